@@ -1,0 +1,166 @@
+/*
+ * spectroplot_hip.h — C ABI of the MI355X-native I/Q STFT -> RGBA hot path.
+ *
+ * This library replaces the compute half of triq-org/spectroplot-js' Web Worker (lib/worker.js `renderFft`):
+ * sample decode -> taper -> radix-2 DFT -> |X|^2 -> dB -> colour index -> RGBA, plus the worker's side outputs
+ * (two histograms, dBfs min/max, three per-frame gauges).  One `sp_context` corresponds to one reference Worker
+ * instance (lib/spectroplot.js:85-116): it owns one HIP stream on one device and processes requests in order.
+ *
+ * Reference interface each entry point replaces (file:line relative to the reference checkout):
+ *
+ *   sp_format_parse          lib/samples.js:22-162      the format-name table (aliases, unknown -> CU8)
+ *   sp_slice_bounds          lib/samples.js:253-258     SampleView.slice: the caller's per-worker byte range
+ *   sp_window                lib/windows.js:14-88       named taper generators (optional sugar; the wire carries arrays)
+ *   sp_twiddles              lib/fft_nayuki.js:42-47    cos/sin tables (exposed for tests)
+ *   sp_plan_create           lib/worker.js:30-62        per-request constants + the cached FFT object
+ *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
+ *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
+ *   sp_synth_*               (none)                     device-side synthetic I/Q for benchmarks
+ *
+ * The request fields are the reference message's (lib/spectroplot.js:1213-1226):
+ *   block_norm, gain, range, cmap -> lut_rgb/lut_len, n, windowc, width, buffer -> bytes/nbytes, format, channelMode,
+ *   waterfall; `offset` is only echoed by the worker and stays in the host wrapper.
+ * The reply fields are the reference reply's (lib/worker.js:140-155):
+ *   cB_hist[1000], c_hist[lut_len], dBfs_min, dBfs_max, gauge_mins/maxs/amps[width], imageData.data[4*width*n].
+ *
+ * Numerics: the DFT runs in IEEE f64 with the reference's exact butterfly graph and operation order (no FMA
+ * contraction), so |X|^2 is bit-identical to the reference's; colour and histogram indices are taken from exact
+ * threshold tables built on the host with a restatement of the engine's Math.log10.  There is no CPU fallback:
+ * without a HIP device every compute entry point returns SP_ERR_NO_DEVICE.
+ *
+ * All functions return SP_OK (0) or a negative status; sp_last_error(ctx) gives a message for the last failure on ctx.
+ */
+#ifndef SPECTROPLOT_HIP_H
+#define SPECTROPLOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_VERSION 100          /* 0.1.0 */
+#define SP_CB_HIST_SIZE 1000    /* centi-bel histogram bins, lib/worker.js:41 */
+#define SP_MAX_LUT 4096         /* largest colour map accepted */
+#define SP_MAX_N (1 << 20)      /* largest FFT length accepted */
+
+enum sp_status {
+    SP_OK = 0,
+    SP_ERR_INVALID_ARG = -1,
+    SP_ERR_NOT_POW2 = -2,        /* reference: throw 'Length is not a power of 2' (lib/fft_nayuki.js:38-39) */
+    SP_ERR_BYTE_LENGTH = -3,     /* reference: RangeError, byte length not a multiple of the view's element size */
+    SP_ERR_UNSUPPORTED = -4,     /* valid for the reference but outside this library's limits (documented per call) */
+    SP_ERR_NO_DEVICE = -5,
+    SP_ERR_HIP = -6,
+    SP_ERR_NOMEM = -7
+};
+
+/* sample formats, lib/samples.js:30-155 */
+enum sp_format {
+    SP_FMT_CU4 = 0, SP_FMT_CS4, SP_FMT_CU8, SP_FMT_CS8, SP_FMT_CU12, SP_FMT_CS12, SP_FMT_CU16, SP_FMT_CS16,
+    SP_FMT_CU32, SP_FMT_CS32, SP_FMT_CU64, SP_FMT_CS64, SP_FMT_CF32, SP_FMT_CF64, SP_FMT_COUNT
+};
+
+typedef struct sp_context sp_context;
+typedef struct sp_plan sp_plan;
+
+/* One render request minus the sample buffer (the reference message, lib/spectroplot.js:1213-1226). Host pointers. */
+typedef struct sp_request {
+    int32_t format;          /* enum sp_format */
+    int32_t n;               /* FFT length, power of two, 2 .. SP_MAX_N */
+    int32_t channel_mode;    /* 0 = I/Q, 1 = L/R split (lib/fft_nayuki.js:103-119) */
+    int32_t waterfall;       /* 0 = spectrogram (n rows x width cols), 1 = waterfall (width rows x n cols) */
+    int32_t lut_len;         /* colour map entries, 1 .. SP_MAX_LUT */
+    int32_t reserved;
+    double block_norm;       /* 1 / sum(taper) */
+    double gain;             /* dB */
+    double range;            /* dB, finite and > 0 */
+    const double *windowc;   /* [n] evaluated taper */
+    const uint8_t *lut_rgb;  /* [3 * lut_len] r,g,b per entry (ends already forced by the caller if wanted) */
+} sp_request;
+
+/* Reply buffers.  For sp_render these are host pointers, for sp_plan_execute device pointers. Any may be NULL. */
+typedef struct sp_reply {
+    uint8_t *rgba;           /* [4 * width * n] */
+    uint8_t *gauge_mins;     /* [width] */
+    uint8_t *gauge_maxs;     /* [width] */
+    uint8_t *gauge_amps;     /* [width] */
+    uint64_t *c_hist;        /* [lut_len]  (sp_plan_execute ADDS into it; zero it first) */
+    uint64_t *cb_hist;       /* [SP_CB_HIST_SIZE]  (likewise) */
+    double *dbfs_minmax;     /* [2] = {dBfs_min, dBfs_max} */
+} sp_reply;
+
+int sp_version(void);
+const char *sp_status_string(int status);
+const char *sp_last_error(const sp_context *ctx);
+
+/* ---- pure host helpers (no device needed) ------------------------------------------------------------- */
+
+/* Maps a format name (any case, aliases, unknown -> CU8) to its id and bytes per complex sample. */
+int sp_format_parse(const char *name, int32_t *format, int32_t *sample_width);
+/* Element size of the typed view the reference lays over the buffer (byte length must be a multiple of it). */
+int sp_format_element_size(int32_t format);
+/* The caller's slice `index` of `count` over a capture of `nbytes` bytes: [*begin, *end) in bytes. */
+int sp_slice_bounds(size_t nbytes, int32_t sample_width, int32_t index, int32_t count, size_t *begin, size_t *end);
+/* Named tapers: "rectangular", "bartlett", "hamming", "hann", "blackman", "blackmanHarris" (exact names). */
+int sp_window(const char *name, int32_t n, double *window, double *weight);
+/* cosTable / sinTable of the reference's FFT object, n/2 entries each. */
+int sp_twiddles(int32_t n, double *cos_table, double *sin_table);
+/* The engine's Math.log10 as restated by this library (exposed so tests can pin it). */
+double sp_js_log10(double x);
+
+/* ---- device ------------------------------------------------------------------------------------------- */
+
+int sp_device_count(int32_t *count);
+/* One context = one reference Worker: one device, one stream, in-order execution. */
+int sp_context_create(int32_t device, sp_context **ctx);
+void sp_context_destroy(sp_context *ctx);
+/* Uses an existing hipStream_t instead of the context's own (e.g. the caller's framework stream). NULL restores. */
+int sp_context_set_stream(sp_context *ctx, void *hip_stream);
+int sp_context_synchronize(sp_context *ctx);
+
+/*
+ * renderFft on host buffers: copies `bytes` to the device, renders, copies the reply back, synchronously.
+ * Plans are cached inside the context while n / taper / LUT / gain / range / block_norm stay the same, as the
+ * reference caches its FFT object (lib/worker.js:59-62).
+ */
+int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+
+/* Pre-evaluated request constants resident on the device: twiddles, taper, RGBA LUT, threshold tables. */
+int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **plan);
+void sp_plan_destroy(sp_plan *plan);
+/*
+ * The frame loop on device-resident operands, asynchronous on the context's stream.
+ * d_bytes: device pointer to the raw capture (nbytes bytes, 16-byte aligned); reply: device pointers.
+ * Histograms are accumulated into reply->c_hist / cb_hist.
+ */
+int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
+/* Name of the kernel variant sp_plan_execute would launch for this width ("lds_r16", "scratch_radix2", ...). */
+const char *sp_plan_kernel_name(const sp_plan *plan);
+/* Forces the portable scratch-memory kernel (tests compare the two device paths). 0 = automatic. */
+int sp_plan_force_kernel(sp_plan *plan, int32_t which);
+
+/* Device memory helpers so that non-HIP hosts (Node, ctypes) can keep operands resident. */
+int sp_device_alloc(sp_context *ctx, size_t nbytes, void **d_ptr);
+int sp_device_free(sp_context *ctx, void *d_ptr);
+int sp_device_upload(sp_context *ctx, void *d_dst, const void *src, size_t nbytes);
+int sp_device_download(sp_context *ctx, void *dst, const void *d_src, size_t nbytes);
+int sp_device_memset(sp_context *ctx, void *d_ptr, int value, size_t nbytes);
+
+/*
+ * Benchmark input: fills d_bytes with `count` samples of the seeded tone + noise signal (definition: DESIGN.md,
+ * tests/siggen.py 'trinoise'), starting at global sample index t0.  Bit-identical to the CPU generators.
+ */
+int sp_synth_trinoise(sp_context *ctx, void *d_bytes, int32_t format, uint64_t t0, uint64_t count,
+                      uint32_t seed, uint32_t step, uint32_t gshift, double amp, double namp);
+
+/* Elapsed milliseconds of the last sp_plan_execute's main kernel on this context (HIP events on its stream). */
+int sp_context_last_kernel_ms(sp_context *ctx, float *ms);
+/* Enables (1) / disables (0) per-execute HIP event timing; off by default. */
+int sp_context_enable_timing(sp_context *ctx, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,271 @@
+"""ctypes binding of include/spectroplot_hip.h.  No compute happens in Python."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SP_CB_HIST_SIZE = 1000
+FORMATS = ["CU4", "CS4", "CU8", "CS8", "CU12", "CS12", "CU16", "CS16", "CU32", "CS32", "CU64", "CS64", "CF32", "CF64"]
+
+SP_ERR_NOT_POW2 = -2
+SP_ERR_BYTE_LENGTH = -3
+SP_ERR_UNSUPPORTED = -4
+SP_ERR_NO_DEVICE = -5
+
+
+class SpectroplotError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s (status %d)" % (message, status))
+        self.status = status
+
+
+class _Request(C.Structure):
+    _fields_ = [("format", C.c_int32), ("n", C.c_int32), ("channel_mode", C.c_int32), ("waterfall", C.c_int32),
+                ("lut_len", C.c_int32), ("reserved", C.c_int32), ("block_norm", C.c_double), ("gain", C.c_double),
+                ("range", C.c_double), ("windowc", C.c_void_p), ("lut_rgb", C.c_void_p)]
+
+
+class _Reply(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("gauge_mins", C.c_void_p), ("gauge_maxs", C.c_void_p), ("gauge_amps", C.c_void_p),
+                ("c_hist", C.c_void_p), ("cb_hist", C.c_void_p), ("dbfs_minmax", C.c_void_p)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libspectroplot_hip.so")
+
+
+def build_library(force=False):
+    """Compiles the HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    target = lib_path()
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return target
+
+
+class Library:
+    """The loaded shared library.  Fails loudly when it has not been built: there is no fallback path."""
+    _instance = None
+
+    def __init__(self, path=None):
+        path = path or lib_path()
+        if not os.path.exists(path):
+            raise SpectroplotError(SP_ERR_NO_DEVICE, "HIP library %s is missing: run __graft_entry__.build() first" % path)
+        L = self.L = C.CDLL(path)
+        self.path = path
+        vp, i32, sz, dbl = C.c_void_p, C.c_int32, C.c_size_t, C.c_double
+        L.sp_version.restype = C.c_int
+        L.sp_status_string.restype = C.c_char_p
+        L.sp_status_string.argtypes = [C.c_int]
+        L.sp_last_error.restype = C.c_char_p
+        L.sp_last_error.argtypes = [vp]
+        L.sp_format_parse.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
+        L.sp_format_element_size.argtypes = [i32]
+        L.sp_slice_bounds.argtypes = [sz, i32, i32, i32, C.POINTER(sz), C.POINTER(sz)]
+        L.sp_window.argtypes = [C.c_char_p, i32, vp, C.POINTER(dbl)]
+        L.sp_twiddles.argtypes = [i32, vp, vp]
+        L.sp_js_log10.restype = dbl
+        L.sp_js_log10.argtypes = [dbl]
+        L.sp_device_count.argtypes = [C.POINTER(i32)]
+        L.sp_context_create.argtypes = [i32, C.POINTER(vp)]
+        L.sp_context_destroy.argtypes = [vp]
+        L.sp_context_destroy.restype = None
+        L.sp_context_set_stream.argtypes = [vp, vp]
+        L.sp_context_synchronize.argtypes = [vp]
+        L.sp_render.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply)]
+        L.sp_plan_create.argtypes = [vp, C.POINTER(_Request), C.POINTER(vp)]
+        L.sp_plan_destroy.argtypes = [vp]
+        L.sp_plan_destroy.restype = None
+        L.sp_plan_execute.argtypes = [vp, vp, sz, i32, C.POINTER(_Reply)]
+        L.sp_plan_kernel_name.restype = C.c_char_p
+        L.sp_plan_kernel_name.argtypes = [vp]
+        L.sp_plan_force_kernel.argtypes = [vp, i32]
+        L.sp_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.sp_device_free.argtypes = [vp, vp]
+        L.sp_device_upload.argtypes = [vp, vp, vp, sz]
+        L.sp_device_download.argtypes = [vp, vp, vp, sz]
+        L.sp_device_memset.argtypes = [vp, vp, C.c_int, sz]
+        L.sp_synth_trinoise.argtypes = [vp, vp, i32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dbl, dbl]
+        L.sp_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.sp_context_enable_timing.argtypes = [vp, i32]
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = Library()
+        return cls._instance
+
+    def check(self, status, ctx=None):
+        if status == 0:
+            return
+        msg = self.L.sp_last_error(ctx).decode() if ctx else ""
+        raise SpectroplotError(status, msg or self.L.sp_status_string(status).decode())
+
+    def device_count(self):
+        n = C.c_int32(0)
+        self.L.sp_device_count(C.byref(n))
+        return n.value
+
+
+def parse_format(name):
+    """(format id, bytes per complex sample) for a reference format name (lib/samples.js:22-162)."""
+    f, w = C.c_int32(), C.c_int32()
+    Library.get().L.sp_format_parse(str(name).encode(), C.byref(f), C.byref(w))
+    return f.value, w.value
+
+
+def slice_bounds(nbytes, sample_width, index, count):
+    b, e = C.c_size_t(), C.c_size_t()
+    lib = Library.get()
+    lib.check(lib.L.sp_slice_bounds(nbytes, sample_width, index, count, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def window(name, n):
+    lib = Library.get()
+    out = np.empty(n, dtype=np.float64)
+    w = C.c_double()
+    lib.check(lib.L.sp_window(name.encode(), n, out.ctypes.data_as(C.c_void_p), C.byref(w)))
+    return out, w.value
+
+
+def twiddles(n):
+    lib = Library.get()
+    c = np.empty(max(n // 2, 1), dtype=np.float64)
+    s = np.empty(max(n // 2, 1), dtype=np.float64)
+    lib.check(lib.L.sp_twiddles(n, c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
+    return c[:n // 2], s[:n // 2]
+
+
+def _make_request(fmt_id, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall):
+    windowc = np.ascontiguousarray(windowc, dtype=np.float64)
+    lut = np.ascontiguousarray(lut, dtype=np.uint8).reshape(-1, 3)
+    req = _Request(fmt_id, int(n), int(bool(channel_mode)), int(bool(waterfall)), len(lut), 0, float(block_norm), float(gain),
+                   float(rng), windowc.ctypes.data_as(C.c_void_p), lut.ctypes.data_as(C.c_void_p))
+    return req, (windowc, lut)
+
+
+class Context:
+    """One device + stream; the analogue of one reference Worker instance."""
+
+    def __init__(self, device=0):
+        self.lib = Library.get()
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.sp_context_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.L.sp_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, status):
+        self.lib.check(status, self.h)
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.L.sp_context_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._chk(self.lib.L.sp_context_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        self._chk(self.lib.L.sp_context_enable_timing(self.h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.L.sp_context_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # -- device memory -----------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.L.sp_device_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self.lib.L.sp_device_free(self.h, C.c_void_p(ptr)))
+
+    def upload(self, d_ptr, array):
+        a = np.ascontiguousarray(array)
+        self._chk(self.lib.L.sp_device_upload(self.h, C.c_void_p(d_ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def download(self, d_ptr, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(self.lib.L.sp_device_download(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), out.nbytes))
+        return out
+
+    def memset(self, d_ptr, value, nbytes):
+        self._chk(self.lib.L.sp_device_memset(self.h, C.c_void_p(d_ptr), value, nbytes))
+
+    def synth_trinoise(self, d_ptr, fmt, t0, count, seed, step, gshift, amp, namp):
+        fid = parse_format(fmt)[0]
+        self._chk(self.lib.L.sp_synth_trinoise(self.h, C.c_void_p(d_ptr), fid, t0, count, seed, step, gshift, amp, namp))
+
+    # -- renderFft on host buffers -------------------------------------------------------------------
+    def render(self, fmt, data, n, windowc, block_norm, gain, rng, lut, width, channel_mode=False, waterfall=False):
+        """Same argument meaning as the reference message; returns the reply fields as numpy arrays."""
+        fid, _ = parse_format(fmt)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        req, keep = _make_request(fid, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)
+        W = int(width)
+        L = len(keep[1])
+        out = {"rgba": np.zeros(4 * max(W, 0) * n, np.uint8), "gauge_mins": np.zeros(max(W, 0), np.uint8),
+               "gauge_maxs": np.zeros(max(W, 0), np.uint8), "gauge_amps": np.zeros(max(W, 0), np.uint8),
+               "c_hist": np.zeros(L, np.uint64), "cB_hist": np.zeros(SP_CB_HIST_SIZE, np.uint64)}
+        mm = np.array([0.0, -200.0])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rep = _Reply(p(out["rgba"]), p(out["gauge_mins"]), p(out["gauge_maxs"]), p(out["gauge_amps"]), p(out["c_hist"]),
+                     p(out["cB_hist"]), p(mm))
+        self._chk(self.lib.L.sp_render(self.h, C.byref(req), p(data), data.size, W, C.byref(rep)))
+        out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])
+        return out
+
+    def plan(self, fmt, n, windowc, block_norm, gain, rng, lut, channel_mode=False, waterfall=False):
+        return Plan(self, fmt, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)
+
+
+class Plan:
+    """Request constants resident on the device; execute() runs the frame loop on device-resident operands."""
+
+    def __init__(self, ctx, fmt, n, windowc, block_norm, gain, rng, lut, channel_mode=False, waterfall=False):
+        self.ctx = ctx
+        self.n = int(n)
+        self.fid, self.sample_width = parse_format(fmt)
+        req, keep = _make_request(self.fid, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)
+        self.lut_len = len(keep[1])
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.L.sp_plan_create(ctx.h, C.byref(req), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.sp_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kernel_name(self):
+        return self.ctx.lib.L.sp_plan_kernel_name(self.h).decode()
+
+    def force_kernel(self, which):
+        self.ctx._chk(self.ctx.lib.L.sp_plan_force_kernel(self.h, {"auto": 0, "scratch": 1, "lds": 2}[which]))
+
+    def execute(self, d_bytes, nbytes, width, rgba=0, gauge_mins=0, gauge_maxs=0, gauge_amps=0, c_hist=0, cb_hist=0, dbfs_minmax=0):
+        """All pointer arguments are device addresses (ints); 0 skips that output. Asynchronous on the context's stream."""
+        rep = _Reply(rgba or None, gauge_mins or None, gauge_maxs or None, gauge_amps or None, c_hist or None, cb_hist or None,
+                     dbfs_minmax or None)
+        self.ctx._chk(self.ctx.lib.L.sp_plan_execute(self.h, C.c_void_p(d_bytes), nbytes, int(width), C.byref(rep)))

@@ -1,0 +1,672 @@
+// sp_api.hip — C ABI of the library (include/spectroplot_hip.h): contexts, plans, the frame-loop launch.
+//
+// One sp_context mirrors one reference Worker instance (lib/spectroplot.js:85-116): requests run in order on
+// its stream.  A plan holds everything the reference computes once per request before its frame loop
+// (lib/worker.js:30-62) plus the threshold tables that stand in for the per-pixel Math.log10.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/spectroplot_hip.h"
+#include "sp_host.h"
+#include "sp_kernel_lds.h"
+#include "sp_kernel_scratch.h"
+#include "sp_synth.h"
+
+namespace {
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            if (hipMalloc(&p, bytes) != hipSuccess) return SP_ERR_NOMEM;
+            want = bytes;
+        }
+        cap = want;
+        return SP_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct sp_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    int cu_count = 256;
+    // workspace of the frame loop
+    DeviceBuffer frame_minmax;   // 2 * width doubles
+    DeviceBuffer partial;        // finish-kernel partials
+    DeviceBuffer scratch;        // scratch kernel slabs
+    // staging for sp_render (host-buffer entry point)
+    DeviceBuffer in_bytes, out_rgba, render_small, hist_dummy;
+    sp_plan *cached_plan = nullptr;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+struct sp_plan {
+    sp_context *ctx = nullptr;
+    sp_request req{};               // windowc / lut_rgb pointers are NOT kept (copied below)
+    std::vector<double> window;
+    std::vector<uint8_t> lut;
+    int levels = 0;
+    spfmt::Format fmt{};
+    double block_norm_db = 0;
+    float gray_a = 0, gray_b = 0, cb_a = 0, cb_b = 0;
+    DeviceBuffer tables;            // one allocation, carved below
+    const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
+    const uint32_t *d_lut = nullptr;
+    const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
+    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds
+};
+
+namespace {
+
+int fail(sp_context *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+int hip_fail(sp_context *ctx, hipError_t e, const char *what)
+{
+    return fail(ctx, SP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SP_HIP(ctx, call)                                            \
+    do {                                                             \
+        hipError_t e_ = (call);                                      \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #call);     \
+    } while (0)
+
+template <typename F>
+int dispatch_format(int32_t fmt, F &&f)
+{
+    switch (fmt) {
+#define SP_CASE(X) case X: return f(std::integral_constant<int, X>{});
+        SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CU8) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12)
+        SP_CASE(SP_FMT_CS12) SP_CASE(SP_FMT_CU16) SP_CASE(SP_FMT_CS16) SP_CASE(SP_FMT_CU32) SP_CASE(SP_FMT_CS32)
+        SP_CASE(SP_FMT_CU64) SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32) SP_CASE(SP_FMT_CF64)
+#undef SP_CASE
+    default: return SP_ERR_INVALID_ARG;
+    }
+}
+
+int validate_request(sp_context *ctx, const sp_request *r)
+{
+    if (!r) return fail(ctx, SP_ERR_INVALID_ARG, "request is null");
+    if (r->format < 0 || r->format >= SP_FMT_COUNT) return fail(ctx, SP_ERR_INVALID_ARG, "unknown format id");
+    if (r->n < 1 || sphost::log2_exact(r->n) < 0) return fail(ctx, SP_ERR_NOT_POW2, "Length is not a power of 2");
+    if (r->n < 2) return fail(ctx, SP_ERR_UNSUPPORTED, "n = 1 is not supported (the reference writes no pixels for it)");
+    if (r->n > SP_MAX_N) return fail(ctx, SP_ERR_UNSUPPORTED, "n exceeds SP_MAX_N");
+    if (r->lut_len < 1 || r->lut_len > SP_MAX_LUT) return fail(ctx, SP_ERR_UNSUPPORTED, "lut_len must be 1..SP_MAX_LUT");
+    if (!r->windowc || !r->lut_rgb) return fail(ctx, SP_ERR_INVALID_ARG, "windowc / lut_rgb is null");
+    if (!(r->range > 0) || !std::isfinite(r->range)) return fail(ctx, SP_ERR_UNSUPPORTED, "range must be finite and > 0");
+    if (!std::isfinite(r->gain)) return fail(ctx, SP_ERR_UNSUPPORTED, "gain must be finite");
+    return SP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------- host helpers
+
+extern "C" int sp_version(void) { return SP_VERSION; }
+
+extern "C" const char *sp_status_string(int status)
+{
+    switch (status) {
+    case SP_OK: return "ok";
+    case SP_ERR_INVALID_ARG: return "invalid argument";
+    case SP_ERR_NOT_POW2: return "Length is not a power of 2";
+    case SP_ERR_BYTE_LENGTH: return "byte length is not a multiple of the element size";
+    case SP_ERR_UNSUPPORTED: return "unsupported by this library";
+    case SP_ERR_NO_DEVICE: return "no HIP device";
+    case SP_ERR_HIP: return "HIP runtime error";
+    case SP_ERR_NOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *sp_last_error(const sp_context *ctx) { return ctx ? ctx->error.c_str() : ""; }
+
+extern "C" int sp_format_parse(const char *name, int32_t *format, int32_t *sample_width)
+{
+    const int32_t id = sphost::parse_format(name ? name : "");
+    if (format) *format = id;
+    if (sample_width) *sample_width = spfmt::describe(id).width;
+    return SP_OK;
+}
+
+extern "C" int sp_format_element_size(int32_t format)
+{
+    if (format < 0 || format >= SP_FMT_COUNT) return SP_ERR_INVALID_ARG;
+    return spfmt::describe(format).elem;
+}
+
+extern "C" int sp_slice_bounds(size_t nbytes, int32_t sample_width, int32_t index, int32_t count, size_t *begin, size_t *end)
+{
+    if (sample_width < 1 || count < 1 || index < 0 || index >= count || !begin || !end) return SP_ERR_INVALID_ARG;
+    const size_t end_sample = nbytes / (size_t)sample_width;                     // ~~(byteLength / sampleWidth)
+    const size_t slice_len = (size_t)sample_width * (end_sample / (size_t)count);  // sampleWidth * ~~(samples / count)
+    *begin = slice_len * (size_t)index;
+    *end = slice_len * ((size_t)index + 1);
+    return SP_OK;
+}
+
+extern "C" int sp_window(const char *name, int32_t n, double *window, double *weight)
+{
+    if (!name || n < 1 || !window || !weight) return SP_ERR_INVALID_ARG;
+    return sphost::window(name, n, window, weight) ? SP_OK : SP_ERR_INVALID_ARG;
+}
+
+extern "C" int sp_twiddles(int32_t n, double *cos_table, double *sin_table)
+{
+    if (n < 1 || sphost::log2_exact(n) < 0) return SP_ERR_NOT_POW2;
+    if (!cos_table || !sin_table) return SP_ERR_INVALID_ARG;
+    sphost::twiddles(n, cos_table, sin_table);
+    return SP_OK;
+}
+
+extern "C" double sp_js_log10(double x) { return spjs::log10(x); }
+
+// ------------------------------------------------------------------------------------------------- contexts
+
+extern "C" int sp_device_count(int32_t *count)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    if (count) *count = c;
+    return c > 0 ? SP_OK : SP_ERR_NO_DEVICE;
+}
+
+extern "C" int sp_context_create(int32_t device, sp_context **out)
+{
+    if (!out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return SP_ERR_NO_DEVICE;
+    if (device < 0 || device >= c) return SP_ERR_INVALID_ARG;
+    sp_context *ctx = new (std::nothrow) sp_context;
+    if (!ctx) return SP_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return SP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return SP_OK;
+}
+
+extern "C" void sp_context_destroy(sp_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->cached_plan) sp_plan_destroy(ctx->cached_plan);
+    ctx->frame_minmax.release();
+    ctx->partial.release();
+    ctx->scratch.release();
+    ctx->in_bytes.release();
+    ctx->out_rgba.release();
+    ctx->render_small.release();
+    ctx->hist_dummy.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int sp_context_set_stream(sp_context *ctx, void *hip_stream)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SP_OK;
+}
+
+extern "C" int sp_context_synchronize(sp_context *ctx)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_context_enable_timing(sp_context *ctx, int32_t on)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    ctx->timing = on != 0;
+    ctx->timed = false;
+    return SP_OK;
+}
+
+extern "C" int sp_context_last_kernel_ms(sp_context *ctx, float *ms)
+{
+    if (!ctx || !ms) return SP_ERR_INVALID_ARG;
+    if (!ctx->timed) return fail(ctx, SP_ERR_INVALID_ARG, "no timed execute on this context");
+    SP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    SP_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- device memory
+
+extern "C" int sp_device_alloc(sp_context *ctx, size_t nbytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(d_ptr, nbytes ? nbytes : 1) != hipSuccess) return fail(ctx, SP_ERR_NOMEM, "hipMalloc failed");
+    return SP_OK;
+}
+
+extern "C" int sp_device_free(sp_context *ctx, void *d_ptr)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SP_HIP(ctx, hipFree(d_ptr));
+    return SP_OK;
+}
+
+extern "C" int sp_device_upload(sp_context *ctx, void *d_dst, const void *src, size_t nbytes)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipMemcpyAsync(d_dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_device_download(sp_context *ctx, void *dst, const void *d_src, size_t nbytes)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipMemcpyAsync(dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_device_memset(sp_context *ctx, void *d_ptr, int value, size_t nbytes)
+{
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipMemsetAsync(d_ptr, value, nbytes, ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_synth_trinoise(sp_context *ctx, void *d_bytes, int32_t format, uint64_t t0, uint64_t count, uint32_t seed,
+                                 uint32_t step, uint32_t gshift, double amp, double namp)
+{
+    if (!ctx || !d_bytes) return SP_ERR_INVALID_ARG;
+    if (format < 0 || format >= SP_FMT_COUNT) return fail(ctx, SP_ERR_INVALID_ARG, "unknown format id");
+    if (count == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const spk::SynthArgs a{(uint8_t *)d_bytes, t0, count, seed, step, gshift, amp, namp};
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ctx, SP_ERR_UNSUPPORTED, "synth: too many samples for one launch");
+    const int rc = dispatch_format(format, [&](auto F) {
+        hipLaunchKernelGGL(spk::k_synth_trinoise<decltype(F)::value>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        return SP_OK;
+    });
+    if (rc) return rc;
+    SP_HIP(ctx, hipGetLastError());
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- plans
+
+extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **out)
+{
+    if (!ctx || !out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = validate_request(ctx, req);
+    if (rc) return rc;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+
+    sp_plan *p = new (std::nothrow) sp_plan;
+    if (!p) return fail(ctx, SP_ERR_NOMEM, "out of host memory");
+    p->ctx = ctx;
+    p->req = *req;
+    p->window.assign(req->windowc, req->windowc + req->n);
+    p->lut.assign(req->lut_rgb, req->lut_rgb + 3 * (size_t)req->lut_len);
+    p->req.windowc = nullptr;
+    p->req.lut_rgb = nullptr;
+    p->levels = sphost::log2_exact(req->n);
+    p->fmt = spfmt::describe(req->format);
+
+    const int n = req->n, half = n / 2, L = req->lut_len;
+    std::vector<double> ct((size_t)half), st((size_t)half);
+    sphost::twiddles(n, ct.data(), st.data());
+    const sphost::PixelMath pm(req->block_norm, req->gain, req->range, L);
+    const sphost::Thresholds th = sphost::build_thresholds(pm, L);
+    p->block_norm_db = pm.block_norm_db;
+    p->gray_a = th.gray_a;
+    p->gray_b = th.gray_b;
+    p->cb_a = th.cb_a;
+    p->cb_b = th.cb_b;
+    std::vector<uint32_t> lut32((size_t)L);
+    for (int i = 0; i < L; i++)
+        lut32[(size_t)i] = (uint32_t)p->lut[3 * (size_t)i] | ((uint32_t)p->lut[3 * (size_t)i + 1] << 8)
+                           | ((uint32_t)p->lut[3 * (size_t)i + 2] << 16) | 0xff000000u;
+    // per-stage twiddle tables for the LDS kernel: stage s (size 2^s) has 2^(s-1) entries (cos, sin), consecutive
+    std::vector<double2> stage_tw;
+    if (spk::lds_kernel_supports(n)) {
+        stage_tw.resize((size_t)n);   // entries 1 .. n-1 used: stage s starts at 2^(s-1)
+        stage_tw[0] = make_double2(0, 0);
+        for (int s = 1; s <= p->levels; s++) {
+            const int cnt = 1 << (s - 1);
+            for (int m = 0; m < cnt; m++) {
+                const int k = m << (p->levels - s);
+                stage_tw[(size_t)(cnt + m)] = make_double2(ct[(size_t)k], st[(size_t)k]);
+            }
+        }
+    }
+
+    // one device allocation: [window n][cos half][sin half][gray_edge L][cb_edge 1001][stage_tw 2n doubles][lut L u32]
+    const size_t nd = (size_t)n + 2 * (size_t)half + (size_t)L + (SP_CB_HIST_SIZE + 1) + 2 * stage_tw.size();
+    const size_t bytes = nd * sizeof(double) + (size_t)L * sizeof(uint32_t);
+    rc = p->tables.reserve(bytes);
+    if (rc) {
+        delete p;
+        return fail(ctx, rc, "plan tables: out of device memory");
+    }
+    std::vector<uint8_t> host(bytes);
+    double *h = (double *)host.data();
+    double *d = (double *)p->tables.p;
+    size_t o = 0;
+    auto put = [&](const void *src, size_t count) {
+        if (count) memcpy(h + o, src, count * sizeof(double));
+        const double *dev = d + o;
+        o += count;
+        return dev;
+    };
+    p->d_window = put(p->window.data(), (size_t)n);
+    p->d_cos = put(ct.data(), (size_t)half);
+    p->d_sin = put(st.data(), (size_t)half);
+    p->d_gray_edge = put(th.gray_edge.data(), (size_t)L);
+    p->d_cb_edge = put(th.cb_edge.data(), SP_CB_HIST_SIZE + 1);
+    p->d_stage_tw = (const double2 *)put(stage_tw.data(), 2 * stage_tw.size());
+    memcpy(h + o, lut32.data(), (size_t)L * sizeof(uint32_t));
+    p->d_lut = (const uint32_t *)(d + o);
+    hipError_t e = hipMemcpyAsync(p->tables.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        p->tables.release();
+        delete p;
+        return hip_fail(ctx, e, "plan table upload");
+    }
+    *out = p;
+    return SP_OK;
+}
+
+extern "C" void sp_plan_destroy(sp_plan *plan)
+{
+    if (!plan) return;
+    if (plan->ctx) {
+        (void)hipSetDevice(plan->ctx->device);
+        (void)hipStreamSynchronize(plan->ctx->stream);
+        if (plan->ctx->cached_plan == plan) plan->ctx->cached_plan = nullptr;
+    }
+    plan->tables.release();
+    delete plan;
+}
+
+extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
+{
+    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
+    if (which == 2 && !spk::lds_kernel_supports(plan->req.n)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this n");
+    plan->force_kernel = which;
+    return SP_OK;
+}
+
+static bool plan_uses_lds(const sp_plan *plan)
+{
+    if (plan->force_kernel == 1) return false;
+    return spk::lds_kernel_supports(plan->req.n);
+}
+
+extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
+{
+    if (!plan) return "";
+    return plan_uses_lds(plan) ? "lds_r16" : "scratch_radix2";
+}
+
+extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *out)
+{
+    if (!plan || !out) return SP_ERR_INVALID_ARG;
+    sp_context *ctx = plan->ctx;
+    if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
+    if (nbytes && !d_bytes) return fail(ctx, SP_ERR_INVALID_ARG, "d_bytes is null");
+    const spfmt::Format f = plan->fmt;
+    if (nbytes % (size_t)f.elem) return fail(ctx, SP_ERR_BYTE_LENGTH, "byte length is not a multiple of the element size");
+    const int n = plan->req.n;
+    const double sample_count = (double)nbytes / (double)f.width;                 // samples.js:167
+    if (sample_count >= 2147483648.0 - (double)n)
+        return fail(ctx, SP_ERR_UNSUPPORTED, "captures of 2^31 samples or more must be sliced (sample positions are int32)");
+    if ((double)width * (double)n > 4e12) return fail(ctx, SP_ERR_UNSUPPORTED, "image too large");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    if (width == 0) {
+        // nothing to draw; the reply keeps the loop's initial values (worker.js:35-36)
+        if (out->dbfs_minmax) {
+            static const double init[2] = {0.0, -200.0};
+            SP_HIP(ctx, hipMemcpyAsync(out->dbfs_minmax, init, sizeof init, hipMemcpyHostToDevice, s));
+            SP_HIP(ctx, hipStreamSynchronize(s));
+        }
+        return SP_OK;
+    }
+
+    const double stride = (sample_count - (double)n) / (double)(width - 1);        // worker.js:50
+    // do all frames lie inside the buffer?
+    bool in_bounds = false;
+    {
+        const double last_d = 0.5 + stride * (double)(width - 1);
+        if (width == 1) {
+            in_bounds = (size_t)n * (size_t)f.width <= nbytes;
+        } else if (stride >= 0.0 && std::isfinite(stride) && last_d < 2147483647.0) {
+            const int64_t last = spjs::to_int32(last_d);
+            in_bounds = (size_t)(last + n) * (size_t)f.width <= nbytes;
+        }
+    }
+
+    int rc = ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
+    if (rc) return fail(ctx, rc, "workspace: out of device memory");
+    const int finish_blocks = (width + spk::kFinishThreads - 1) / spk::kFinishThreads;
+    rc = ctx->partial.reserve(2 * (size_t)finish_blocks * sizeof(double));
+    if (rc) return fail(ctx, rc, "workspace: out of device memory");
+
+    spk::FrameArgs a{};
+    a.bytes = (const uint8_t *)d_bytes;
+    a.nbytes = (int64_t)nbytes;
+    a.nelem = (int64_t)(nbytes / (size_t)f.elem);
+    a.stride = stride;
+    a.n = n;
+    a.levels = plan->levels;
+    a.width = width;
+    a.channel_mode = plan->req.channel_mode ? 1 : 0;
+    a.waterfall = plan->req.waterfall ? 1 : 0;
+    a.lut_len = plan->req.lut_len;
+    a.in_bounds = in_bounds ? 1 : 0;
+    a.frame0 = 0;
+    a.window = plan->d_window;
+    a.cos_t = plan->d_cos;
+    a.sin_t = plan->d_sin;
+    a.gray_edge = plan->d_gray_edge;
+    a.cb_edge = plan->d_cb_edge;
+    a.lut_rgba = plan->d_lut;
+    a.gray_a = plan->gray_a;
+    a.gray_b = plan->gray_b;
+    a.cb_a = plan->cb_a;
+    a.cb_b = plan->cb_b;
+    a.rgba = out->rgba;
+    a.frame_min = (double *)ctx->frame_minmax.p;
+    a.frame_max = a.frame_min + width;
+    a.scratch = nullptr;
+
+    // histograms are optional for the caller but the kernels always count: point them at scratch space if absent
+    DeviceBuffer &small = ctx->hist_dummy;
+    unsigned long long *c_hist = (unsigned long long *)out->c_hist, *cb_hist = (unsigned long long *)out->cb_hist;
+    if (!c_hist || !cb_hist) {
+        rc = small.reserve((SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(uint64_t));
+        if (rc) return fail(ctx, rc, "workspace: out of device memory");
+        if (!c_hist) c_hist = (unsigned long long *)small.p;
+        if (!cb_hist) cb_hist = (unsigned long long *)small.p + SP_MAX_LUT;
+    }
+    a.c_hist = c_hist;
+    a.cb_hist = cb_hist;
+
+    if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    if (plan_uses_lds(plan)) {
+        rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
+        if (rc) return fail(ctx, rc, "LDS kernel launch rejected the configuration");
+    } else {
+        // scratch slabs: one per workgroup, capped at 256 MiB
+        long long blocks = (256ll << 20) / (16ll * n);
+        if (blocks > width) blocks = width;
+        if (blocks > 4 * ctx->cu_count) blocks = 4 * ctx->cu_count;
+        if (blocks < 1) blocks = 1;
+        rc = ctx->scratch.reserve((size_t)blocks * 2 * (size_t)n * sizeof(double));
+        if (rc) return fail(ctx, rc, "scratch: out of device memory");
+        a.scratch = (double *)ctx->scratch.p;
+        rc = dispatch_format(plan->req.format, [&](auto F) {
+            hipLaunchKernelGGL(spk::k_scratch_radix2<decltype(F)::value>, dim3((unsigned)blocks), dim3(spk::kScratchThreads), 0, s, a);
+            return SP_OK;
+        });
+        if (rc) return fail(ctx, rc, "bad format");
+    }
+    SP_HIP(ctx, hipGetLastError());
+    if (ctx->timing) {
+        SP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->timed = true;
+    }
+
+    spk::FinishArgs fa{};
+    fa.bytes = a.bytes;
+    fa.nbytes = a.nbytes;
+    fa.nelem = a.nelem;
+    fa.stride = stride;
+    fa.n = n;
+    fa.width = width;
+    fa.format = plan->req.format;
+    fa.block_norm_db = plan->block_norm_db;
+    fa.gain = plan->req.gain;
+    fa.range = plan->req.range;
+    fa.frame_min = a.frame_min;
+    fa.frame_max = a.frame_max;
+    fa.gauge_mins = out->gauge_mins;
+    fa.gauge_maxs = out->gauge_maxs;
+    fa.gauge_amps = out->gauge_amps;
+    fa.partial = (double *)ctx->partial.p;
+    hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);
+    if (out->dbfs_minmax)
+        hipLaunchKernelGGL(spk::k_finish_reduce, dim3(1), dim3(256), 0, s, (const double *)ctx->partial.p, finish_blocks, out->dbfs_minmax);
+    SP_HIP(ctx, hipGetLastError());
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- host-buffer render
+
+static bool same_request(const sp_plan *p, const sp_request *r)
+{
+    const sp_request &q = p->req;
+    if (q.format != r->format || q.n != r->n || q.channel_mode != r->channel_mode || q.waterfall != r->waterfall
+        || q.lut_len != r->lut_len)
+        return false;
+    if (memcmp(&q.block_norm, &r->block_norm, 8) || memcmp(&q.gain, &r->gain, 8) || memcmp(&q.range, &r->range, 8)) return false;
+    if (memcmp(p->window.data(), r->windowc, sizeof(double) * (size_t)r->n)) return false;
+    return memcmp(p->lut.data(), r->lut_rgb, 3 * (size_t)r->lut_len) == 0;
+}
+
+extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply)
+{
+    if (!ctx || !reply) return SP_ERR_INVALID_ARG;
+    int rc = validate_request(ctx, req);
+    if (rc) return rc;
+    if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
+    if (nbytes && !bytes) return fail(ctx, SP_ERR_INVALID_ARG, "bytes is null");
+    // the reference constructs its typed view before anything else (worker.js:24)
+    if (nbytes % (size_t)spfmt::describe(req->format).elem)
+        return fail(ctx, SP_ERR_BYTE_LENGTH, "byte length is not a multiple of the element size");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+
+    if (!ctx->cached_plan || !same_request(ctx->cached_plan, req)) {
+        if (ctx->cached_plan) sp_plan_destroy(ctx->cached_plan);
+        ctx->cached_plan = nullptr;
+        rc = sp_plan_create(ctx, req, &ctx->cached_plan);
+        if (rc) return rc;
+    }
+    sp_plan *plan = ctx->cached_plan;
+    hipStream_t s = ctx->stream;
+
+    const size_t W = (size_t)width, n = (size_t)req->n, L = (size_t)req->lut_len;
+    const size_t rgba_bytes = 4 * W * n;
+    rc = ctx->in_bytes.reserve(nbytes + 16);
+    if (!rc) rc = ctx->out_rgba.reserve(rgba_bytes + 16);
+    // small outputs: [c_hist L u64][cb_hist 1000 u64][minmax 2 f64][gauges 3*W u8]
+    const size_t small_u64 = L + SP_CB_HIST_SIZE + 2;
+    DeviceBuffer &small = ctx->render_small;
+    if (!rc) rc = small.reserve(small_u64 * 8 + 3 * W + 16);
+    if (rc) return fail(ctx, rc, "sp_render: out of device memory");
+    uint64_t *d_c = (uint64_t *)small.p, *d_cb = d_c + L;
+    double *d_mm = (double *)(d_cb + SP_CB_HIST_SIZE);
+    uint8_t *d_g = (uint8_t *)(d_mm + 2);
+
+    hipError_t e = hipSuccess;
+    if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(small.p, 0, small_u64 * 8, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
+    sp_reply d{};
+    d.rgba = reply->rgba ? (uint8_t *)ctx->out_rgba.p : nullptr;
+    d.gauge_mins = d_g;
+    d.gauge_maxs = d_g + W;
+    d.gauge_amps = d_g + 2 * W;
+    d.c_hist = d_c;
+    d.cb_hist = d_cb;
+    d.dbfs_minmax = d_mm;
+    rc = sp_plan_execute(plan, ctx->in_bytes.p, nbytes, width, &d);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    auto down = [&](void *dst, const void *src, size_t bytes_) {
+        if (dst && bytes_ && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, s);
+    };
+    down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
+    down(reply->gauge_mins, d.gauge_mins, W);
+    down(reply->gauge_maxs, d.gauge_maxs, W);
+    down(reply->gauge_amps, d.gauge_amps, W);
+    down(reply->c_hist, d_c, L * 8);
+    down(reply->cb_hist, d_cb, SP_CB_HIST_SIZE * 8);
+    down(reply->dbfs_minmax, d_mm, 16);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "sp_render download");
+    return SP_OK;
+}

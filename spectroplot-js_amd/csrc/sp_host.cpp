@@ -1,0 +1,155 @@
+// sp_host.cpp — host-side tables (see sp_host.h).  Compiled with -ffp-contract=off.
+#include "sp_host.h"
+
+#include <cctype>
+#include <cmath>
+#include <cstring>
+
+namespace sphost {
+
+int32_t parse_format(const char *name)
+{
+    char f[24];
+    size_t i = 0;
+    for (; name && name[i] && i + 1 < sizeof f; i++) f[i] = (char)toupper((unsigned char)name[i]);
+    f[i] = 0;
+    static const struct { const char *name; int32_t id; } table[] = {
+        {"CU4", SP_FMT_CU4}, {"CS4", SP_FMT_CS4}, {"CU8", SP_FMT_CU8}, {"DATA", SP_FMT_CU8}, {"COMPLEX16U", SP_FMT_CU8},
+        {"CS8", SP_FMT_CS8}, {"COMPLEX16S", SP_FMT_CS8}, {"CU16", SP_FMT_CU16}, {"CS16", SP_FMT_CS16},
+        {"CU12", SP_FMT_CU12}, {"CS12", SP_FMT_CS12}, {"CU32", SP_FMT_CU32}, {"CS32", SP_FMT_CS32},
+        {"CU64", SP_FMT_CU64}, {"CS64", SP_FMT_CS64}, {"CF32", SP_FMT_CF32}, {"CFILE", SP_FMT_CF32},
+        {"COMPLEX", SP_FMT_CF32}, {"CF64", SP_FMT_CF64},
+    };
+    for (const auto &e : table)
+        if (!strcmp(f, e.name)) return e.id;
+    return SP_FMT_CU8;   // lib/samples.js:149-155: default
+}
+
+int32_t log2_exact(int64_t n)
+{
+    for (int32_t i = 0; i < 31; i++)
+        if (((int64_t)1 << i) == n) return i;
+    return -1;
+}
+
+static const double kPi = 3.141592653589793;   // Math.PI
+
+void twiddles(int32_t n, double *cos_table, double *sin_table)
+{
+    for (int32_t i = 0; i < n / 2; i++) {
+        const double a = 2 * kPi * (double)i / (double)n;
+        cos_table[i] = spjs::cos(a);
+        sin_table[i] = spjs::sin(a);
+    }
+}
+
+bool window(const char *name, int32_t n, double *out, double *weight)
+{
+    enum { RECT, BARTLETT, HAMMING, HANN, BLACKMAN, BH } kind;
+    if (!strcmp(name, "rectangular")) kind = RECT;
+    else if (!strcmp(name, "bartlett")) kind = BARTLETT;
+    else if (!strcmp(name, "hamming")) kind = HAMMING;
+    else if (!strcmp(name, "hann")) kind = HANN;
+    else if (!strcmp(name, "blackman")) kind = BLACKMAN;
+    else if (!strcmp(name, "blackmanHarris")) kind = BH;
+    else return false;
+    const double m = (double)(n - 1);
+    double sum = 0.0;
+    for (int32_t k = 0; k < n; k++) {
+        const double i = (double)k;
+        double w = 1.0;
+        switch (kind) {
+        case RECT: break;
+        case BARTLETT: w = 1.0 - std::fabs((i - 0.5 * m) / (0.5 * m)); break;
+        case HAMMING: w = 0.54 - 0.46 * spjs::cos(2.0 * kPi * i / m); break;
+        case HANN: w = 0.5 * (1.0 - spjs::cos(2.0 * kPi * i / m)); break;
+        case BLACKMAN:
+            w = 0.42 - (0.5 * spjs::cos((2.0 * kPi * i) / m)) + (0.08 * spjs::cos((4.0 * kPi * i) / m));
+            break;
+        case BH:
+            w = 0.35875 - (0.48829 * spjs::cos((2.0 * kPi * i) / m)) + (0.14128 * spjs::cos((4.0 * kPi * i) / m))
+                - (0.01168 * spjs::cos((6.0 * kPi * i) / m));
+            break;
+        }
+        out[k] = w;
+        sum += w;
+    }
+    *weight = sum;
+    return true;
+}
+
+PixelMath::PixelMath(double block_norm, double gain_, double range_, int32_t lut_len)
+    : block_norm_db(10 * spjs::log10(block_norm)), gain(gain_), range(range_), color_max((double)(lut_len - 1)),
+      color_norm((double)lut_len / -range_)
+{
+}
+
+double PixelMath::dbfs(double abs2) const { return 5 * spjs::log10(abs2) + block_norm_db + gain; }
+double PixelMath::rel_db(double abs2) const { return dbfs(abs2) - gain; }
+
+int32_t PixelMath::gray(double abs2) const
+{
+    const double u = color_max - dbfs(abs2) * color_norm;
+    return spjs::to_int32(0.5 + (u < 0 ? 0 : u > color_max ? color_max : u));
+}
+
+int32_t PixelMath::centibel(double abs2) const { return spjs::to_int32(0.5 + rel_db(abs2) * -10); }
+
+namespace {
+
+const uint64_t kMinPos = 1;                        // smallest subnormal
+const uint64_t kMaxFinite = 0x7fefffffffffffffull;
+
+// smallest positive finite double (as bits) at which pred becomes true; pred must be monotone false -> true
+template <typename Pred>
+double first_true(uint64_t lo, Pred pred)
+{
+    if (pred(spjs::from_bits(lo))) return spjs::from_bits(lo);
+    uint64_t hi = kMaxFinite;
+    if (!pred(spjs::from_bits(hi))) return spjs::inf();
+    // invariant: pred(lo) false, pred(hi) true
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (pred(spjs::from_bits(mid))) hi = mid;
+        else lo = mid;
+    }
+    return spjs::from_bits(hi);
+}
+
+}  // namespace
+
+Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
+{
+    Thresholds t;
+    t.gray_edge.assign((size_t)lut_len, 0.0);
+    t.cb_edge.assign(SP_CB_HIST_SIZE + 1, 0.0);
+
+    uint64_t lo = kMinPos;
+    for (int32_t g = 1; g < lut_len; g++) {
+        const double e = first_true(lo, [&](double a) { return pm.gray(a) >= g; });
+        t.gray_edge[(size_t)g] = e;
+        if (e != spjs::inf()) lo = spjs::bits(e);   // edges are non-decreasing
+    }
+    auto level = [&](double a) {
+        const int32_t cb = pm.centibel(a);
+        if (cb < 0) return SP_CB_HIST_SIZE;
+        return SP_CB_HIST_SIZE - 1 - (cb > SP_CB_HIST_SIZE - 1 ? SP_CB_HIST_SIZE - 1 : cb);
+    };
+    lo = kMinPos;
+    for (int32_t j = 1; j <= SP_CB_HIST_SIZE; j++) {
+        const double e = first_true(lo, [&](double a) { return level(a) >= j; });
+        t.cb_edge[(size_t)j] = e;
+        if (e != spjs::inf()) lo = spjs::bits(e);
+    }
+
+    // first guesses: dbfs = 5*log10(2)*log2(abs2) + block_norm_db + gain
+    const double c = 5.0 * 0.30102999566398120;
+    const double per_db = (double)lut_len / pm.range;
+    t.gray_a = (float)(pm.color_max + 0.5 + per_db * (pm.block_norm_db + pm.gain));
+    t.gray_b = (float)(per_db * c);
+    t.cb_a = (float)((SP_CB_HIST_SIZE - 1) - 0.5 + 10.0 * pm.block_norm_db);
+    t.cb_b = (float)(10.0 * c);
+    return t;
+}
+
+}  // namespace sphost

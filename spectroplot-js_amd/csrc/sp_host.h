@@ -1,0 +1,53 @@
+// sp_host.h — host-side tables of a render plan: format names, tapers, twiddles and the exact threshold tables that
+// replace the per-pixel Math.log10 of the reference.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sp_formats.h"
+
+namespace sphost {
+
+// lib/samples.js:22-162: upper-cased name -> format; aliases; everything unknown is CU8.
+int32_t parse_format(const char *name);
+
+// lib/fft_nayuki.js:33-39
+int32_t log2_exact(int64_t n);
+
+// lib/fft_nayuki.js:42-47: cos(2*pi*i/n), sin(2*pi*i/n), i < n/2
+void twiddles(int32_t n, double *cos_table, double *sin_table);
+
+// lib/windows.js:14-88; returns false for an unknown name
+bool window(const char *name, int32_t n, double *out, double *weight);
+
+// The per-pixel arithmetic of lib/worker.js:92-113 as a function of abs2 = re^2 + im^2.
+struct PixelMath {
+    double block_norm_db;   // 10 * log10(block_norm)                      worker.js:31
+    double gain, range;
+    double color_max;       // lut_len - 1                                  worker.js:37
+    double color_norm;      // lut_len / -range                             worker.js:38
+
+    PixelMath(double block_norm, double gain, double range, int32_t lut_len);
+    double dbfs(double abs2) const;        // 5*log10(abs2) + block_norm_db + gain        worker.js:93
+    double rel_db(double abs2) const;      // dbfs - gain                                  worker.js:102-105
+    int32_t gray(double abs2) const;       // colour index                                 worker.js:111-112
+    int32_t centibel(double abs2) const;   // ~~(0.5 + rel_db * -10), before the 999 cap   worker.js:105
+};
+
+// Threshold tables: for finite abs2 > 0 both indices are monotone step functions of abs2, so
+//   gray(abs2)  = #{ g in 1..lut_len-1 : abs2 >= gray_edge[g] }            (gray_edge[0] = 0)
+//   level(abs2) = #{ j in 1..1000      : abs2 >= cb_edge[j] }              (cb_edge[0] = 0)
+//   cB bin      = 999 - level, dropped when level == 1000 (negative key in the reference)
+// abs2 == 0, +inf and NaN take bin 0 (ToInt32 of an infinity / NaN is 0) and are handled by the kernels.
+// Unreachable edges are +inf.  Edges are the smallest doubles at which the restated arithmetic changes its result.
+struct Thresholds {
+    std::vector<double> gray_edge;   // [lut_len]
+    std::vector<double> cb_edge;     // [1001]
+    // first-guess coefficients for the kernels: index ~= a + b * log2(abs2)
+    float gray_a, gray_b, cb_a, cb_b;
+};
+Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len);
+
+}  // namespace sphost

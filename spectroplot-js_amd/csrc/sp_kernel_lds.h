@@ -1,0 +1,457 @@
+// sp_kernel_lds.h — the fast frame-loop kernel for 64 <= n <= 8192 (gfx950).
+//
+// Shape of the work (lib/worker.js:68-137 per frame): n samples in, n RGBA pixels out, an n-point DFT in between whose
+// butterfly graph and f64 operation order are fixed by bit-exactness with lib/fft_nayuki.js:54-96.  There is no dense
+// contraction here, so no MFMA: the kernel is f64-VALU work fed from HBM through registers, with LDS used only to
+// re-distribute points between register passes and to transpose the colour indices for coalesced image stores.
+//
+// Decomposition
+//   * 16 points per thread, T = n/16 threads per frame (one wave = one frame at n = 1024).  A 512-thread workgroup
+//     runs 8192/n frames at a time.
+//   * The radix-2 DIT graph is executed as register passes of <= 4 consecutive stages.  During a pass a thread owns
+//     the 16 positions that differ in a 4-bit "window" [ws, ws+4) of the position index; every butterfly of those
+//     stages pairs two of its own registers.  Between passes the 16 values go through LDS (real parts, then
+//     imaginary parts, through the same padded buffer) and come back under the next window.  The arithmetic of each
+//     butterfly is exactly the reference's: 4 multiplies, 2 adds for the twiddle product, 4 adds/subtracts, each
+//     rounded on its own (compile with -ffp-contract=off).
+//   * Pass 0 (stages 1-4, window [0,4)) has compile-time twiddle indices (scalar loads); later passes read
+//     per-stage twiddle tables whose entries are consecutive across lanes.
+//   * Input: thread tl of a frame owns positions 16*tl + e, i.e. samples rev4(e)*T + rev(tl): every load instruction
+//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.
+//   * Epilogue: |X|^2 in f64 -> colour index and centi-bel bin by a v_log_f32 first guess corrected against exact
+//     edge tables in LDS (no f64 log per pixel) -> LDS histograms (clipped ends counted in registers) ->
+//     one byte per pixel into an LDS tile [frame][bin] -> after F frames the workgroup writes the tile out through
+//     the RGBA LUT as 16-byte stores: 128-byte row segments in spectrogram layout, whole rows in waterfall layout.
+//   * Per-frame min/max of |X|^2 go to HBM; the finish kernel turns them into gauges and the dBfs range.
+#pragma once
+
+#include "sp_kernels_common.h"
+
+namespace spk {
+
+constexpr int kLdsThreads = 512;
+constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
+constexpr int kLdsMaxLut = 1024;
+constexpr int kTilePad = 4;   // tile row pitch = n + 4 bytes: conflict-free dword reads across 8 frame quads
+
+__host__ __device__ inline bool lds_kernel_supports(int n)
+{
+    return n >= (1 << kLdsMinLog2) && n <= (1 << kLdsMaxLog2) && (n & (n - 1)) == 0;
+}
+
+// frames per output group (tile height)
+__host__ __device__ inline int lds_group_frames(int n, int want)
+{
+    const int fpb = kLdsThreads * 16 / n;   // frames per round
+    int f = 32768 / n;
+    if (f > want) f = want;
+    if (f < fpb) f = fpb;
+    if (f < 4) f = 4;
+    return f;
+}
+
+struct LdsLayout {
+    int xch_doubles;   // exchange buffer (all frames of a round)
+    int tile_bytes;
+    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, total;
+};
+
+__host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_frames)
+{
+    LdsLayout l;
+    const int fpb = kLdsThreads * 16 / n;
+    l.xch_doubles = fpb * (n + n / 16);
+    l.tile_bytes = group_frames * (n + kTilePad);
+    int o = l.xch_doubles * 8;
+    l.off_gedge = o;  o += lut_len * 8;
+    l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
+    l.off_mm = o;     o += group_frames * 8 * 2 * 8;   // up to 8 wave partials per frame, {min,max}
+    l.off_tile = o;   o += (l.tile_bytes + 15) & ~15;
+    l.off_lut = o;    o += lut_len * 4;
+    l.off_chist = o;  o += lut_len * 4;
+    l.off_cbhist = o; o += SP_CB_HIST_SIZE * 4;
+    l.total = (o + 15) & ~15;
+    return l;
+}
+
+__device__ inline constexpr int rev4(int e) { return ((e & 1) << 3) | ((e & 2) << 1) | ((e & 4) >> 1) | ((e & 8) >> 3); }
+
+// position owned by (thread tl, register e) under window start ws
+__device__ inline int win_pos(int tl, int e, int ws) { return (tl & ((1 << ws) - 1)) | (e << ws) | ((tl >> ws) << (ws + 4)); }
+__device__ inline int pad_idx(int p) { return p + (p >> 4); }
+
+// One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
+template <int WS, int S0, int S1>
+__device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ stage_tw)
+{
+#pragma unroll
+    for (int s = S0; s <= S1; s++) {
+        const int u = (s - 1) - WS;          // bit of the register index toggled by this stage
+        const int half = 1 << (s - 1);
+        const int tl_low = tl & ((1 << WS) - 1);
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0++) {
+            if (e0 & (1 << u)) continue;
+            const int e1 = e0 | (1 << u);
+            // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
+            const int m = tl_low | ((e0 & ((1 << u) - 1)) << WS);
+            const double2 w = stage_tw[half + m];
+            const double c = w.x, sn = w.y;
+            const double rl = re[e1], il = im[e1];
+            const double tpre = rl * c + il * sn;          // fft_nayuki.js:80
+            const double tpim = il * c - rl * sn;          // fft_nayuki.js:81  (-rl*sn + il*c)
+            const double rj = re[e0], ij = im[e0];
+            re[e1] = rj - tpre;
+            im[e1] = ij - tpim;
+            re[e0] = rj + tpre;
+            im[e0] = ij + tpim;
+        }
+    }
+}
+
+template <bool BLOCK_SYNC>
+__device__ inline void frame_sync()
+{
+    if constexpr (BLOCK_SYNC) {
+        __syncthreads();
+    } else {
+        // the frame lives in one wave: LDS operations of a wave execute in order, only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Re-distribute the 16 values of every thread from window WS_FROM to window WS_TO through the frame's LDS buffer.
+template <int WS_FROM, int WS_TO, bool BLOCK_SYNC>
+__device__ inline void exchange(double (&v)[16], int tl, double *__restrict__ buf)
+{
+    frame_sync<BLOCK_SYNC>();   // previous readers are done with buf
+#pragma unroll
+    for (int e = 0; e < 16; e++) buf[pad_idx(win_pos(tl, e, WS_FROM))] = v[e];
+    frame_sync<BLOCK_SYNC>();
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = buf[pad_idx(win_pos(tl, e, WS_TO))];
+}
+
+template <int FMT>
+__device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, int64_t start, int tl, int T, int levels,
+                                  const double (&win)[16], double (&re)[16], double (&im)[16])
+{
+    const int sidx = (int)(__brev((unsigned)tl) >> (32 - (levels - 4)));   // rev_{L-4}(tl)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int64_t pos = start + rev4(e) * T + sidx;
+        double vi, vq;
+        if (a.in_bounds) {
+            spfmt::sample_fast<FMT>(a.bytes, pos, vi, vq);
+        } else {
+            vi = spfmt::sample_checked<FMT>(view, pos, 0);
+            vq = spfmt::sample_checked<FMT>(view, pos, 1);
+        }
+        re[e] = win[e] * vi;                                                   // worker.js:73-74
+        im[e] = win[e] * vq;
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
+                                                         const int group_frames, const int groups)
+{
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / 16;                       // threads per frame
+    constexpr int FPB = kLdsThreads / T;            // frames per round
+    constexpr bool BLOCK_SYNC = T > 64;
+    constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
+    constexpr int NPASS = (LOG2N + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
+    double *s_xch = (double *)smem;
+    double *s_gedge = (double *)(smem + lay.off_gedge);
+    double *s_cbedge = (double *)(smem + lay.off_cbedge);
+    double *s_mm = (double *)(smem + lay.off_mm);
+    unsigned char *s_tile = smem + lay.off_tile;
+    unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
+    unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);
+    unsigned int *s_cbhist = (unsigned int *)(smem + lay.off_cbhist);
+
+    const int tid = threadIdx.x;
+    const int fs = tid / T;                         // frame slot within a round
+    const int tl = tid % T;                         // thread within the frame
+    double *xbuf = s_xch + fs * (N + N / 16);
+    const int tile_pitch = N + kTilePad;
+    const int cmax = a.lut_len - 1;
+
+    for (int i = tid; i < a.lut_len; i += kLdsThreads) {
+        s_gedge[i] = a.gray_edge[i];
+        s_lut[i] = a.lut_rgba[i];
+        s_chist[i] = 0;
+    }
+    for (int i = tid; i <= SP_CB_HIST_SIZE; i += kLdsThreads) s_cbedge[i] = a.cb_edge[i];
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads) s_cbhist[i] = 0;
+
+    // taper coefficients of this thread's 16 samples stay in registers for the whole launch
+    double win[16];
+    {
+        const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+#pragma unroll
+        for (int e = 0; e < 16; e++) win[e] = a.window[rev4(e) * T + sidx];
+    }
+    __syncthreads();
+
+    const spfmt::View view{a.bytes, a.nbytes, a.nelem};
+    // clipped colour indices and the last centi-bel bin are counted in registers (they dominate typical images)
+    unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
+
+    // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
+    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int chunk = (groups + 7) >> 3;
+    const int g_end = min(groups, (xcd + 1) * chunk);
+
+    for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
+        const int x0 = g * group_frames;
+        for (int r = 0; r < group_frames / FPB; r++) {
+            const int fr = r * FPB + fs;            // frame within the group
+            const int xr = x0 + fr;
+            const bool live = xr < a.width;
+            const int x = live ? xr : a.width - 1;  // surplus slots recompute the last frame and discard it
+            const int64_t start = frame_start(a.stride, x);
+
+            double re[16], im[16];
+            switch (format) {
+#define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im); break;
+                SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CU8) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12)
+                SP_CASE(SP_FMT_CS12) SP_CASE(SP_FMT_CU16) SP_CASE(SP_FMT_CS16) SP_CASE(SP_FMT_CU32) SP_CASE(SP_FMT_CS32)
+                SP_CASE(SP_FMT_CU64) SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32)
+#undef SP_CASE
+            default: load_frame<SP_FMT_CF64>(a, view, start, tl, T, LOG2N, win, re, im); break;
+            }
+
+            // ---- DFT: register passes with LDS re-distribution in between ---------------------------------
+            fft_pass<0, 1, 4>(re, im, tl, stage_tw);
+            if constexpr (NPASS >= 2) {
+                constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
+                constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
+                exchange<0, WS1, BLOCK_SYNC>(re, tl, xbuf);
+                exchange<0, WS1, BLOCK_SYNC>(im, tl, xbuf);
+                fft_pass<WS1, 5, E1>(re, im, tl, stage_tw);
+                if constexpr (NPASS >= 3) {
+                    constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
+                    constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
+                    exchange<WS1, WS2, BLOCK_SYNC>(re, tl, xbuf);
+                    exchange<WS1, WS2, BLOCK_SYNC>(im, tl, xbuf);
+                    fft_pass<WS2, 9, E2>(re, im, tl, stage_tw);
+                    if constexpr (NPASS >= 4) {
+                        constexpr int WS3 = LOG2N - 4;
+                        exchange<WS2, WS3, BLOCK_SYNC>(re, tl, xbuf);
+                        exchange<WS2, WS3, BLOCK_SYNC>(im, tl, xbuf);
+                        fft_pass<WS3, 13, LOG2N>(re, im, tl, stage_tw);
+                    }
+                }
+            }
+            // now register e of thread tl holds bin i = tl + e*T
+
+            if (a.channel_mode) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
+                double pr[16], pi[16];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) pr[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = im[e];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) pi[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = tl + e * T;
+                    const double orr = re[e], oi = im[e];
+                    if (i == 0) {
+                        im[e] = 0.0;
+                    } else if (i == N / 2) {
+                        re[e] = 0.0;
+                        im[e] = 0.0;
+                    } else if (i < N / 2) {
+                        re[e] = 0.5 * (orr + pr[e]);
+                        im[e] = 0.5 * (oi - pi[e]);
+                    } else {
+                        re[e] = 0.5 * (pi[e] + oi);
+                        im[e] = 0.5 * (-pr[e] + orr);
+                    }
+                }
+            }
+
+            // ---- |X|^2 -> indices ---------------------------------------------------------------------------
+            double mn = spjs::inf(), mx = 0.0;
+            unsigned char *trow = s_tile + fr * tile_pitch;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const double abs2 = re[e] * re[e] + im[e] * im[e];                 // worker.js:92
+                mn = min_nn(mn, abs2);
+                mx = max_nn(mx, abs2);
+                // first guess from the hardware log2 on the mantissa, exact result from the edge tables
+                int ex;
+                const double mant = frexp(abs2, &ex);
+                const float l2 = (float)ex + __log2f((float)mant);
+                int gr = (int)fminf(fmaxf(floorf(a.gray_a + a.gray_b * l2), 0.0f), (float)cmax);
+                while (gr < cmax && abs2 >= s_gedge[gr + 1]) gr++;
+                while (gr > 0 && !(abs2 >= s_gedge[gr])) gr--;
+                int bin;
+                if (!(abs2 > 0.0) || abs2 == spjs::inf()) {
+                    bin = 0;
+                } else {
+                    int lv = (int)fminf(fmaxf(floorf(a.cb_a + a.cb_b * l2), 0.0f), (float)SP_CB_HIST_SIZE);
+                    while (lv < SP_CB_HIST_SIZE && abs2 >= s_cbedge[lv + 1]) lv++;
+                    while (lv > 0 && !(abs2 >= s_cbedge[lv])) lv--;
+                    bin = SP_CB_HIST_SIZE - 1 - lv;
+                }
+                if (cmax < 256) trow[tl + e * T] = (unsigned char)gr;
+                if (live) {
+                    if (gr == 0) cnt_g0++;
+                    else if (gr == cmax) cnt_gmax++;
+                    else atomicAdd(&s_chist[gr], 1u);
+                    if (bin == SP_CB_HIST_SIZE - 1) cnt_cb_last++;
+                    else if (bin == 0) cnt_cb0++;
+                    else if (bin > 0) atomicAdd(&s_cbhist[bin], 1u);
+                }
+                if (cmax >= 256) {
+                    // colour maps longer than 256 entries do not fit the byte tile: store the pixel directly
+                    if (live && a.rgba) *(uint32_t *)(a.rgba + pixel_offset(N, a.width, a.waterfall, x, tl + e * T)) = s_lut[gr];
+                }
+            }
+            // frame min / max over its T threads
+#pragma unroll
+            for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) {
+                mn = min_nn(mn, __shfl_xor(mn, off));
+                mx = max_nn(mx, __shfl_xor(mx, off));
+            }
+            if constexpr (WPF == 1) {
+                if (tl == 0 && live) {
+                    a.frame_min[x] = mn;
+                    a.frame_max[x] = mx;
+                }
+            } else {
+                if ((tl & 63) == 0) {
+                    s_mm[(fr * 8 + (tl >> 6)) * 2] = mn;
+                    s_mm[(fr * 8 + (tl >> 6)) * 2 + 1] = mx;
+                }
+            }
+        }
+        __syncthreads();   // tile complete
+
+        if constexpr (WPF > 1) {
+            if (tid < group_frames && x0 + tid < a.width) {
+                double mn = s_mm[tid * 16], mx = s_mm[tid * 16 + 1];
+                for (int w = 1; w < WPF; w++) {
+                    mn = min_nn(mn, s_mm[(tid * 8 + w) * 2]);
+                    mx = max_nn(mx, s_mm[(tid * 8 + w) * 2 + 1]);
+                }
+                a.frame_min[x0 + tid] = mn;
+                a.frame_max[x0 + tid] = mx;
+            }
+        }
+
+        // ---- tile -> RGBA -------------------------------------------------------------------------------------
+        if (a.rgba && cmax < 256) {
+            if (!a.waterfall) {
+                // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
+                // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
+                const int quads = group_frames / 4;                 // frame quads per row
+                const int items = (N / 4) * quads;
+                for (int it = tid; it < items; it += kLdsThreads) {
+                    const int fq = it % quads, bq = it / quads;
+                    const int f0 = fq * 4, i0 = bq * 4;
+                    uint32_t gb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) gb[k] = *(const uint32_t *)(s_tile + (f0 + k) * tile_pitch + i0);
+                    const int xa = x0 + f0;
+                    if (xa >= a.width) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = i0 + j;
+                        const int y = (N / 2 - i) & (N - 1);
+                        uint32_t px[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) px[k] = s_lut[(gb[k] >> (8 * j)) & 0xff];
+                        uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+                        if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                            *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (xa + k < a.width) ((uint32_t *)dst)[k] = px[k];
+                        }
+                    }
+                }
+            } else {
+                // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
+                const int items = group_frames * (N / 4);
+                for (int it = tid; it < items; it += kLdsThreads) {
+                    const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
+                    const int xa = x0 + f;
+                    if (xa >= a.width) continue;
+                    const unsigned char *row = s_tile + f * tile_pitch;
+                    uint32_t px[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) px[k] = s_lut[row[(c4 + k + N / 2 + 1) & (N - 1)]];
+                    uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
+                    *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
+                }
+            }
+        }
+        __syncthreads();   // tile and s_mm are reused by the next group
+    }
+
+    // ---- flush histograms ----------------------------------------------------------------------------------------
+    if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
+    if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
+    if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
+    if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
+    __syncthreads();
+    for (int i = tid; i < a.lut_len; i += kLdsThreads)
+        if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads)
+        if (s_cbhist[i]) atomicAdd(&a.cb_hist[i], (unsigned long long)s_cbhist[i]);
+}
+
+// Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
+inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, hipStream_t stream)
+{
+    if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut) return SP_ERR_UNSUPPORTED;
+    const int n = a.n;
+    // tile height: 32 frames give 128-byte row segments; small images use shorter groups so every CU gets work
+    int want = 32;
+    while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
+    const int gf = lds_group_frames(n, want);
+    const int groups = (a.width + gf - 1) / gf;
+    const LdsLayout lay = lds_layout(n, a.lut_len, gf);
+    int grid = groups < cu_count ? groups : cu_count;
+    grid = (grid + 7) & ~7;
+
+#define SP_LAUNCH(L)                                                                                                     \
+    case L: {                                                                                                            \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute((const void *)k_lds_r16<L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)   \
+                != hipSuccess)                                                                                           \
+                return SP_ERR_HIP;                                                                                       \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL(k_lds_r16<L>, dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a, format, \
+                           stage_tw, gf, groups);                                                                        \
+        break;                                                                                                           \
+    }
+    if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
+    switch (a.levels) {
+        SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8) SP_LAUNCH(9) SP_LAUNCH(10) SP_LAUNCH(11) SP_LAUNCH(12) SP_LAUNCH(13)
+    default: return SP_ERR_UNSUPPORTED;
+    }
+#undef SP_LAUNCH
+    return SP_OK;
+}
+
+}  // namespace spk

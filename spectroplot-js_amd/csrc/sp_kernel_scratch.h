@@ -1,0 +1,233 @@
+// sp_kernel_scratch.h — the portable frame-loop kernel: one workgroup per frame, the frame kept in an HBM/L2
+// scratch slab, one radix-2 stage per barrier.  It handles every (format, n, width, stride, layout) the library
+// accepts, including out-of-range frames and n beyond what fits in LDS.  It is the fallback behind the LDS kernel
+// (sp_kernel_lds.h) and the in-library cross-check for it; it is not the fast path.
+#pragma once
+
+#include "sp_kernels_common.h"
+
+namespace spk {
+
+constexpr int kScratchThreads = 256;
+
+__device__ inline uint32_t bit_reverse(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
+
+template <int FMT>
+__global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameArgs a)
+{
+    __shared__ unsigned int s_c_hist[SP_MAX_LUT];
+    __shared__ unsigned int s_cb_hist[SP_CB_HIST_SIZE];
+    __shared__ double s_red[2 * (kScratchThreads / 64)];
+
+    const int tid = threadIdx.x;
+    const int n = a.n;
+    double *re = a.scratch + (size_t)blockIdx.x * 2 * (size_t)n;
+    double *im = re + n;
+    const spfmt::View view{a.bytes, a.nbytes, a.nelem};
+
+    for (int i = tid; i < a.lut_len; i += kScratchThreads) s_c_hist[i] = 0;
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kScratchThreads) s_cb_hist[i] = 0;
+    __syncthreads();
+
+    for (int x = a.frame0 + blockIdx.x; x < a.width; x += gridDim.x) {
+        const int64_t start = frame_start(a.stride, x);
+
+        // decode + taper, stored in bit-reversed order (fft_nayuki.js:57-69)            worker.js:70-75
+        for (int k = tid; k < n; k += kScratchThreads) {
+            double vi, vq;
+            if (a.in_bounds) {
+                spfmt::sample_fast<FMT>(a.bytes, start + k, vi, vq);
+            } else {
+                vi = spfmt::sample_checked<FMT>(view, start + k, 0);
+                vq = spfmt::sample_checked<FMT>(view, start + k, 1);
+            }
+            const double w = a.window[k];
+            const uint32_t j = a.levels ? bit_reverse((uint32_t)k, a.levels) : 0;
+            re[j] = w * vi;
+            im[j] = w * vq;
+        }
+        __syncthreads();
+
+        // radix-2 decimation in time, same butterfly arithmetic as fft_nayuki.js:72-88
+        for (int s = 1; s <= a.levels; s++) {
+            const int half = 1 << (s - 1);
+            for (int b = tid; b < (n >> 1); b += kScratchThreads) {
+                const int lowbits = b & (half - 1);
+                const int j = ((b >> (s - 1)) << s) | lowbits;
+                const int l = j + half;
+                const int k = lowbits << (a.levels - s);
+                const double c = a.cos_t[k], sn = a.sin_t[k];
+                const double rl = re[l], il = im[l];
+                const double tpre = rl * c + il * sn;
+                const double tpim = -rl * sn + il * c;
+                const double rj = re[j], ij = im[j];
+                re[l] = rj - tpre;
+                im[l] = ij - tpim;
+                re[j] = rj + tpre;
+                im[j] = ij + tpim;
+            }
+            __syncthreads();
+        }
+
+        if (a.channel_mode) {   // fft_nayuki.js:103-119
+            for (int i = 1 + tid; i < (n >> 1); i += kScratchThreads) {
+                const double ra = re[i], rb = re[n - i], ia = im[i], ib = im[n - i];
+                re[i] = 0.5 * (ra + rb);
+                im[i] = 0.5 * (ia - ib);
+                re[n - i] = 0.5 * (ia + ib);
+                im[n - i] = 0.5 * (-ra + rb);
+            }
+            if (tid == 0) {
+                im[0] = 0.0;
+                re[n >> 1] = 0.0;   // = imag[0], already zeroed in the reference
+                im[n >> 1] = 0.0;
+            }
+            __syncthreads();
+        }
+
+        // |X|^2 -> indices -> histograms -> RGBA                                          worker.js:85-122
+        double mn = spjs::inf(), mx = 0.0;
+        for (int i = tid; i < n; i += kScratchThreads) {
+            const double r = re[i], q = im[i];
+            const double abs2 = r * r + q * q;
+            mn = min_nn(mn, abs2);
+            mx = max_nn(mx, abs2);
+            const int gray = gray_exact(a.gray_edge, a.lut_len, abs2);
+            const int bin = cb_bin_exact(a.cb_edge, abs2);
+            atomicAdd(&s_c_hist[gray], 1u);
+            if (bin >= 0) atomicAdd(&s_cb_hist[bin], 1u);
+            if (a.rgba) *(uint32_t *)(a.rgba + pixel_offset(n, a.width, a.waterfall, x, i)) = a.lut_rgba[gray];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = min_nn(mn, __shfl_xor(mn, off));
+            mx = max_nn(mx, __shfl_xor(mx, off));
+        }
+        if ((tid & 63) == 0) {
+            s_red[2 * (tid >> 6)] = mn;
+            s_red[2 * (tid >> 6) + 1] = mx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kScratchThreads / 64; w++) {
+                mn = min_nn(mn, s_red[2 * w]);
+                mx = max_nn(mx, s_red[2 * w + 1]);
+            }
+            a.frame_min[x] = mn;
+            a.frame_max[x] = mx;
+        }
+        __syncthreads();   // scratch slab and s_red are reused by the next frame
+    }
+
+    for (int i = tid; i < a.lut_len; i += kScratchThreads)
+        if (s_c_hist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_c_hist[i]);
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kScratchThreads)
+        if (s_cb_hist[i]) atomicAdd(&a.cb_hist[i], (unsigned long long)s_cb_hist[i]);
+}
+
+// ---- per-frame side outputs (worker.js:124-136) and the global dBfs range (worker.js:124-125) -----------
+
+struct FinishArgs {
+    const uint8_t *bytes;
+    int64_t nbytes, nelem;
+    double stride;
+    int32_t n, width, format;
+    double block_norm_db, gain, range;
+    const double *frame_min, *frame_max;
+    uint8_t *gauge_mins, *gauge_maxs, *gauge_amps;
+    double *partial;   // [gridDim.x * 2]
+};
+
+// store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
+__device__ inline uint8_t clamp_u8(double v)
+{
+    if (!(v > 0.0)) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)rint(v);
+}
+
+__device__ inline double centre_sample(int fmt, const spfmt::View &v, int64_t pos, int c)
+{
+    switch (fmt) {
+#define SP_CASE(F) case F: return spfmt::sample_checked<F>(v, pos, c);
+        SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12) SP_CASE(SP_FMT_CS12)
+        SP_CASE(SP_FMT_CU16) SP_CASE(SP_FMT_CS16) SP_CASE(SP_FMT_CU32) SP_CASE(SP_FMT_CS32) SP_CASE(SP_FMT_CU64)
+        SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32) SP_CASE(SP_FMT_CF64)
+#undef SP_CASE
+    default: return spfmt::sample_checked<SP_FMT_CU8>(v, pos, c);
+    }
+}
+
+constexpr int kFinishThreads = 256;
+
+__global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishArgs a)
+{
+    __shared__ double s_red[2 * (kFinishThreads / 64)];
+    const int x = blockIdx.x * kFinishThreads + threadIdx.x;
+    double dmin = 0.0, dmax = -200.0;   // worker.js:35-36
+    if (x < a.width) {
+        // d = dBfs - gain is monotone in abs2, so the frame's extreme d values come from its extreme abs2 values
+        const double dlo = (5 * spjs::log10(a.frame_min[x]) + a.block_norm_db + a.gain) - a.gain;
+        const double dhi = (5 * spjs::log10(a.frame_max[x]) + a.block_norm_db + a.gain) - a.gain;
+        double fmin = 0.0, fmax = -200.0;   // worker.js:82-83
+        if (dlo < fmin) fmin = dlo;
+        if (dhi > fmax) fmax = dhi;
+        dmin = fmin;
+        dmax = fmax;
+        if (a.gauge_mins) a.gauge_mins[x] = clamp_u8(0.5 + (a.range + fmin) * 256 / a.range);
+        if (a.gauge_maxs) a.gauge_maxs[x] = clamp_u8(0.5 + (a.range + fmax) * 256 / a.range);
+        if (a.gauge_amps) {
+            const spfmt::View v{a.bytes, a.nbytes, a.nelem};
+            const int64_t mid = (int64_t)frame_start(a.stride, x) + (a.n >> 1);
+            const double ci = centre_sample(a.format, v, mid, 0), cq = centre_sample(a.format, v, mid, 1);
+            const double amp = 5 * spjs::log10(ci * ci + cq * cq) + a.gain;
+            a.gauge_amps[x] = clamp_u8(0.5 + (a.range + amp) * 256 / a.range);
+        }
+    }
+    // dmin <= 0 and dmax >= -200 are never NaN here
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = fmin(dmin, __shfl_xor(dmin, off));
+        dmax = fmax(dmax, __shfl_xor(dmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[2 * (threadIdx.x >> 6)] = dmin;
+        s_red[2 * (threadIdx.x >> 6) + 1] = dmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kFinishThreads / 64; w++) {
+            dmin = fmin(dmin, s_red[2 * w]);
+            dmax = fmax(dmax, s_red[2 * w + 1]);
+        }
+        a.partial[2 * blockIdx.x] = dmin;
+        a.partial[2 * blockIdx.x + 1] = dmax;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finish_reduce(const double *partial, int count, double *out_minmax)
+{
+    __shared__ double s_red[8];
+    double dmin = 0.0, dmax = -200.0;
+    for (int i = threadIdx.x; i < count; i += 256) {
+        dmin = fmin(dmin, partial[2 * i]);
+        dmax = fmax(dmax, partial[2 * i + 1]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = fmin(dmin, __shfl_xor(dmin, off));
+        dmax = fmax(dmax, __shfl_xor(dmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[2 * (threadIdx.x >> 6)] = dmin;
+        s_red[2 * (threadIdx.x >> 6) + 1] = dmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            dmin = fmin(dmin, s_red[2 * w]);
+            dmax = fmax(dmax, s_red[2 * w + 1]);
+        }
+        out_minmax[0] = dmin;
+        out_minmax[1] = dmax;
+    }
+}
+
+}  // namespace spk

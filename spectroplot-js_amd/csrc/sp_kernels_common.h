@@ -1,0 +1,76 @@
+// sp_kernels_common.h — device-side structures and helpers shared by the frame-loop kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sp_formats.h"
+
+namespace spk {
+
+// Everything one launch of the frame loop (lib/worker.js:68-137) needs; passed by value.
+struct FrameArgs {
+    const uint8_t *bytes;        // raw capture in HBM
+    int64_t nbytes;
+    int64_t nelem;               // length of the reference's typed view over the buffer
+    double stride;               // (sampleCount - n) / (width - 1)                          worker.js:50
+    int32_t n, levels, width;
+    int32_t channel_mode, waterfall, lut_len;
+    int32_t in_bounds;           // every frame lies inside the buffer: unchecked loads are safe
+    int32_t frame0;              // first frame of this launch (always 0 today)
+    const double *window;        // [n]
+    const double *cos_t;         // [n/2]
+    const double *sin_t;         // [n/2]
+    const double *gray_edge;     // [lut_len]
+    const double *cb_edge;       // [1001]
+    const uint32_t *lut_rgba;    // [lut_len] packed r | g<<8 | b<<16 | 255<<24
+    float gray_a, gray_b, cb_a, cb_b;
+    uint8_t *rgba;               // [4*width*n] or nullptr
+    unsigned long long *c_hist;  // [lut_len]   accumulated
+    unsigned long long *cb_hist; // [1000]      accumulated
+    double *frame_min;           // [width] min over the frame of abs2 (NaN ignored), +inf if none
+    double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
+    double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
+};
+
+// frame start: ~~(0.5 + stride * x)                                                          worker.js:72
+__device__ inline int32_t frame_start(double stride, int32_t x) { return spjs::to_int32(0.5 + stride * (double)x); }
+
+// Exact colour index from the edge table: number of edges 1..lut_len-1 that are <= abs2 (NaN -> 0).
+__device__ inline int32_t gray_exact(const double *edge, int32_t lut_len, double abs2)
+{
+    int32_t lo = 0, hi = lut_len - 1;   // answer in [lo, hi]
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (abs2 >= edge[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Exact centi-bel bin: -1 means "dropped" (negative key in the reference).
+__device__ inline int32_t cb_bin_exact(const double *edge, double abs2)
+{
+    if (!(abs2 > 0.0) || abs2 == spjs::inf()) return 0;   // -inf / +inf / NaN dB: ToInt32 gives 0
+    int32_t lo = 0, hi = SP_CB_HIST_SIZE;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (abs2 >= edge[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    return SP_CB_HIST_SIZE - 1 - lo;
+}
+
+// image byte offset of bin i of frame x                                                       worker.js:90,115-117
+__device__ inline size_t pixel_offset(int32_t n, int32_t width, int32_t waterfall, int32_t x, int32_t i)
+{
+    const int32_t half = n >> 1;
+    const int32_t y = i <= half ? half - i : half + n - i;
+    return waterfall ? ((size_t)n * (size_t)(width - 1 - x) + (size_t)(n - 1 - y)) * 4
+                     : ((size_t)x + (size_t)width * (size_t)y) * 4;
+}
+
+// fmin / fmax that ignore NaN operands (v_min_f64 / v_max_f64 semantics)
+__device__ inline double min_nn(double a, double b) { return fmin(a, b); }
+__device__ inline double max_nn(double a, double b) { return fmax(a, b); }
+
+}  // namespace spk

@@ -30,7 +30,7 @@ def _values(gen, t, c):
     if c:
         ph = (ph - 16384) & 0xFFFF
     tri = (np.abs(ph - 32768) - 16384).astype(np.float64) / 16384.0
-    gate = np.where((t >> int(gen["gshift"])) & 1, 1.0, 0.25)
+    gate = np.where(((t & 0xFFFFFFFF) >> int(gen["gshift"])) & 1, 1.0, 0.25)
     u = hash32(gen["seed"], ((2 * t + c) & 0xFFFFFFFF).astype(np.uint32)).astype(np.float64) / 4294967296.0 - 0.5
     return (np.float64(gen["amp"]) * gate) * tri + np.float64(gen["namp"]) * u
 

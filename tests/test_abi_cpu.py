@@ -1,0 +1,105 @@
+"""CPU-only checks of the product library: it loads, exports every symbol the header declares, its host-side tables
+are bit-identical to the reference's (golden KATs), and compute entry points fail loudly without a device."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from goldenlib import same_f64, sha256
+from __graft_entry__ import ROOT, build, load_package
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_package()
+    if not os.path.exists(p.lib_path()):
+        build()
+    return p
+
+
+def test_header_symbols_are_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "spectroplot_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    lib = C.CDLL(pkg.lib_path())
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_oracle_in_product():
+    """The product path must not reach into oracle/ (a CPU fallback would void every parity claim)."""
+    pdir = os.path.join(ROOT, "spectroplot-js_amd")
+    for dirpath, _, files in os.walk(pdir):
+        if os.sep + "build" in dirpath or os.sep + "lib" in dirpath or "node_modules" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".cc", ".js")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in text and "sp_oracle" not in text and "worker_oracle" not in text, f
+
+
+def test_format_table(pkg):
+    # lib/samples.js:22-162
+    want = {"CU4": 1, "CS4": 1, "CU8": 2, "DATA": 2, "COMPLEX16U": 2, "CS8": 2, "COMPLEX16S": 2, "CU16": 4, "CS16": 4, "CU12": 3,
+            "CS12": 3, "CU32": 8, "CS32": 8, "CU64": 16, "CS64": 16, "CF32": 8, "CFILE": 8, "COMPLEX": 8, "CF64": 16,
+            "anything": 2, "": 2, "cs16": 4, "Cf32": 8}
+    for name, sw in want.items():
+        assert pkg.parse_format(name)[1] == sw, name
+    assert pkg.parse_format("cfile")[0] == pkg.parse_format("CF32")[0]
+    assert pkg.parse_format("wav")[0] == pkg.parse_format("CU8")[0]
+
+
+def test_slice_bounds(pkg, golden):
+    # lib/samples.js:253-258 — the golden slice cases record the byte length of every slice
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "slices" not in e:
+            continue
+        sw = pkg.parse_format(c["format"])[1]
+        for i, s in enumerate(e["slices"]):
+            b0, b1 = pkg.slice_bounds(c["bytes"], sw, i, c["slices"])
+            assert b1 - b0 == s["slice_bytes"] and b0 == i * s["slice_bytes"]
+
+
+def test_windows_bit_identical(pkg, golden):
+    idx = json.load(open(golden.file("windows.json")))
+    for e in idx:
+        w, weight = pkg.window(e["name"], e["n"])
+        assert sha256(w) == e["sha256"], (e["name"], e["n"])
+        assert same_f64(weight, e["weight"])
+    with pytest.raises(pkg.SpectroplotError):
+        pkg.window("kaiser", 16)
+
+
+def test_twiddles_bit_identical(pkg, golden):
+    F = json.load(open(golden.file("fft.json")))
+    for t in F["twiddles"]:
+        c, s = pkg.twiddles(t["n"])
+        assert sha256(np.concatenate([c, s])) == t["sha256"], t["n"]
+    with pytest.raises(pkg.SpectroplotError) as ei:
+        pkg.twiddles(12)
+    assert ei.value.status == -2
+
+
+def test_js_log10_bit_identical(pkg, golden):
+    lg = np.fromfile(golden.file("math_log10.bin"), dtype=np.float64)
+    n = len(lg) // 2
+    f = pkg.Library.get().L.sp_js_log10
+    for x, e in zip(lg[:n], lg[n:]):
+        r = f(float(x))
+        assert (r != r and e != e) or np.float64(r).view(np.uint64) == np.float64(e).view(np.uint64), x
+
+
+def test_fails_loudly_without_device(pkg):
+    lib = pkg.Library.get()
+    if lib.device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(pkg.SpectroplotError) as ei:
+        pkg.Context(0)
+    assert ei.value.status == -5
+    with pytest.raises(pkg.SpectroplotError):
+        pkg.HipWorker(0)

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the golden vectors of the real reference worker
+and against the C oracle on seeded inputs.  Bit-exact: RGBA bytes, histograms, gauges and the f64 dBfs range.
+Tolerance: none (every compared quantity is an integer, a byte, or an f64 that is required to be bit-identical)."""
+import numpy as np
+import pytest
+
+import goldenlib
+import siggen
+from __graft_entry__ import load_package
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def _plan_render(pkg, ctx, kernel, fmt, data, n, win, bn, gain, rng, lut, width, channel_mode, waterfall):
+    """Renders through sp_plan_execute with a forced kernel variant (device-resident operands)."""
+    plan = ctx.plan(fmt, n, win, bn, gain, rng, lut, channel_mode, waterfall)
+    try:
+        plan.force_kernel(kernel)
+    except pkg.SpectroplotError:
+        plan.close()
+        return None
+    W, L = int(width), len(lut)
+    d_in = ctx.alloc(max(data.size, 16))
+    ctx.upload(d_in, data) if data.size else None
+    sizes = [4 * W * n, W, W, W, 8 * L, 8000, 16]
+    ptrs = [ctx.alloc(max(s, 16)) for s in sizes]
+    for p, s in zip(ptrs, sizes):
+        ctx.memset(p, 0, max(s, 16))
+    plan.execute(d_in, data.size, W, *ptrs)
+    ctx.synchronize()
+    out = {"rgba": ctx.download(ptrs[0], sizes[0]), "gauge_mins": ctx.download(ptrs[1], W), "gauge_maxs": ctx.download(ptrs[2], W),
+           "gauge_amps": ctx.download(ptrs[3], W), "c_hist": ctx.download(ptrs[4], 8 * L, np.uint64),
+           "cB_hist": ctx.download(ptrs[5], 8000, np.uint64)}
+    mm = ctx.download(ptrs[6], 16, np.float64)
+    out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])
+    out["kernel"] = plan.kernel_name()
+    for p in ptrs + [d_in]:
+        ctx.free(p)
+    plan.close()
+    return out
+
+
+def _case_args(golden, c):
+    data = golden.input(c)
+    win, weight = pyoracle.window(c["window"], c["n"])
+    return data, win, 1.0 / weight, golden.lut(c)
+
+
+def test_golden_worker_cases_sp_render(pkg, ctx, golden):
+    """Every worker vector of the real reference through sp_render (host buffers, automatic kernel choice)."""
+    bad = []
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "reply" not in e and "throws" not in e:
+            continue
+        if "throws" in e and c["n"] & (c["n"] - 1):
+            data, win, bn, lut = golden.input(c), np.ones(c["n"]), 1.0, golden.lut(c)
+        else:
+            data, win, bn, lut = _case_args(golden, c)
+        args = (c["format"], data, c["n"], win, bn, c["gain"], c["range"], lut, c["width"], c["channelMode"], c["waterfall"])
+        if "throws" in e:
+            with pytest.raises(pkg.SpectroplotError) as ei:
+                ctx.render(*args)
+            want = -2 if "power of 2" in e["throws"] else -3
+            assert ei.value.status == want, (c["name"], ei.value.status)
+            continue
+        r = ctx.render(*args)
+        bad += goldenlib.check_reply(r, e["reply"], c["name"] + ": ")
+    assert not bad, bad[:30]
+
+
+@pytest.mark.parametrize("kernel", ["scratch", "lds"])
+def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
+    """The same vectors through sp_plan_execute with each device kernel forced (device-resident operands)."""
+    bad, ran = [], 0
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "reply" not in e or c["width"] == 0:
+            continue
+        data, win, bn, lut = _case_args(golden, c)
+        r = _plan_render(pkg, ctx, kernel, c["format"], data, c["n"], win, bn, c["gain"], c["range"], lut, c["width"],
+                         c["channelMode"], c["waterfall"])
+        if r is None:
+            continue   # this kernel does not cover the case's n
+        ran += 1
+        bad += goldenlib.check_reply(r, e["reply"], "%s[%s]: " % (c["name"], r["kernel"]))
+    assert ran > 50
+    assert not bad, bad[:30]
+
+
+def test_golden_slices_through_worker_mirror(pkg, golden):
+    """The caller's slice + merge (spectroplot.js:1206-1244) over HipWorker instances, against the merged vectors."""
+    w = pkg.HipWorker(0)
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "merged" not in e:
+            continue
+        data = golden.input(c)
+        win, weight = pyoracle.window(c["window"], c["n"])
+        cmap = golden.lut(c, force_ends=False).tolist()
+        m = pkg.render_sliced(w.render, data, c["format"], c["n"], c["width"], c["slices"], win, weight, cmap, c["gain"], c["range"],
+                              c["channelMode"], c["waterfall"], force_ends=c["force_ends"])
+        assert goldenlib.sha256(m["data"]) == e["merged"]["rgba_sha256"], c["name"]
+        assert [int(v) for v in m["c_hist"]] == e["merged"]["c_hist"], c["name"]
+        assert goldenlib.same_f64(m["dBfs_min"], e["merged"]["dBfs_min"]) and goldenlib.same_f64(m["dBfs_max"], e["merged"]["dBfs_max"])
+        assert m["slice_width"] == e["merged"]["slice_width"]
+        for i, r in enumerate(m["replies"]):
+            rr = {"rgba": r["imageData"]["data"], "gauge_mins": r["gauge_mins"], "gauge_maxs": r["gauge_maxs"],
+                  "gauge_amps": r["gauge_amps"], "c_hist": r["c_hist"], "cB_hist": r["cB_hist"], "dBfs_min": r["dBfs_min"],
+                  "dBfs_max": r["dBfs_max"]}
+            assert not goldenlib.check_reply(rr, e["slices"][i]), (c["name"], i)
+    w.terminate()
+
+
+SEEDED = [
+    # fmt, log2 samples, n, width, window, gain, range, channelMode, waterfall
+    ("CF32", 18, 1024, 256, "blackmanHarris", 6, 30, False, False),
+    ("CF32", 17, 1024, 333, "hann", 10, 50, False, True),
+    ("CS16", 18, 2048, 128, "hann", 6, 30, False, False),
+    ("CU8", 18, 1024, 1000, "blackmanHarris", 6, 30, True, False),
+    ("CS12", 17, 8192, 64, "blackmanHarris", 6, 30, False, False),
+    ("CU8", 16, 512, 2048, "hann", 6, 30, False, False),
+    ("CS8", 16, 64, 700, "hamming", 0, 60, False, True),
+    ("CU16", 16, 128, 515, "bartlett", 20, 90, True, True),
+    ("CF64", 15, 4096, 40, "blackman", 6, 30, False, False),
+    ("CS32", 15, 256, 129, "rectangular", 3, 12, False, False),
+]
+
+
+@pytest.mark.parametrize("case", SEEDED, ids=lambda c: "%s_n%d_w%d" % (c[0], c[2], c[3]))
+def test_seeded_inputs_against_oracle(pkg, ctx, golden, case):
+    fmt, lg, n, width, wname, gain, rng, ch, wf = case
+    gen = {"kind": "trinoise", "seed": 99 + n + width, "step": 9173, "gshift": 12, "amp": 0.45, "namp": 0.03}
+    data = siggen.generate(fmt, gen, 1 << lg)
+    win, weight = pyoracle.window(wname, n)
+    lut = golden.lut("viridis", force_ends=True)
+    want = pyoracle.render(fmt, data, n, win, 1.0 / weight, gain, rng, lut, width, ch, wf)
+    got = ctx.render(fmt, data, n, win, 1.0 / weight, gain, rng, lut, width, ch, wf)
+    for k in ("rgba", "gauge_mins", "gauge_maxs", "gauge_amps"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["c_hist"].astype(np.int64), want["c_hist"])
+    assert np.array_equal(got["cB_hist"].astype(np.int64), want["cB_hist"])
+    assert np.float64(got["dBfs_min"]).view(np.uint64) == np.float64(want["dBfs_min"]).view(np.uint64)
+    assert np.float64(got["dBfs_max"]).view(np.uint64) == np.float64(want["dBfs_max"]).view(np.uint64)
+
+
+def test_device_synth_matches_cpu_generator(pkg, ctx):
+    gen = dict(seed=0x5EED0001, step=7321, gshift=11, amp=0.5, namp=0.02)
+    for fmt in pkg.FORMATS:
+        sw = siggen.SAMPLE_WIDTH[fmt]
+        count, t0 = 5000, 123456
+        d = ctx.alloc(count * sw)
+        ctx.synth_trinoise(d, fmt, t0, count, gen["seed"], gen["step"], gen["gshift"], gen["amp"], gen["namp"])
+        ctx.synchronize()
+        got = ctx.download(d, count * sw)
+        ctx.free(d)
+        want = siggen.generate(fmt, dict(kind="trinoise", **gen), count, t0)
+        assert np.array_equal(got, want), fmt
+
+
+def test_full_size_config2_sampled_frames(pkg, ctx, golden):
+    """BASELINE config 2 at full size (16 MSample cf32, n=1024, Blackman-Harris, viridis) on device-generated input:
+    size-independent checks (histogram totals, alpha channel) plus bit-exact comparison of sampled frames with the oracle."""
+    n, S, fmt = 1024, 1 << 24, "CF32"
+    W = S // n
+    gen = dict(seed=0x5EED0001, step=7321, gshift=11, amp=0.5, namp=0.02)
+    win, weight = pyoracle.window("blackmanHarris", n)
+    lut = golden.lut("viridis", force_ends=True)
+    d_in = ctx.alloc(S * 8)
+    ctx.synth_trinoise(d_in, fmt, 0, S, gen["seed"], gen["step"], gen["gshift"], gen["amp"], gen["namp"])
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+    sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+    ptrs = [ctx.alloc(s) for s in sizes]
+    for p, s in zip(ptrs, sizes):
+        ctx.memset(p, 0, s)
+    plan.execute(d_in, S * 8, W, *ptrs)
+    ctx.synchronize()
+    rgba = ctx.download(ptrs[0], sizes[0]).reshape(n, W, 4)
+    c_hist = ctx.download(ptrs[4], 8 * 256, np.uint64)
+    cb_hist = ctx.download(ptrs[5], 8000, np.uint64)
+    gmin, gmax, gamp = (ctx.download(ptrs[i], W) for i in (1, 2, 3))
+    assert int(c_hist.sum()) == W * n
+    assert int(cb_hist.sum()) <= W * n
+    assert (rgba[:, :, 3] == 255).all()
+    # colour histogram of the image equals c_hist (a checksum of checksums)
+    packed = rgba.reshape(-1, 4).view(np.uint32).reshape(-1)
+    lut32 = np.concatenate([lut, np.full((256, 1), 255, np.uint8)], axis=1).view(np.uint32).reshape(-1)
+    assert len(np.unique(lut32)) == 256
+    order = np.argsort(lut32)
+    idx = order[np.searchsorted(lut32[order], packed)]
+    assert np.array_equal(np.bincount(idx, minlength=256).astype(np.uint64), c_hist)
+    rs = np.random.RandomState(7)
+    for x in list(rs.randint(0, W, size=24)) + [0, W - 1]:
+        frame = siggen.generate(fmt, dict(kind="trinoise", **gen), n, t0=int(x) * n)   # stride == n exactly
+        o = pyoracle.render(fmt, frame, n, win, 1.0 / weight, 6.0, 30.0, lut, 1)
+        assert np.array_equal(rgba[:, x, :].reshape(-1), o["rgba"]), x
+        assert gmin[x] == o["gauge_mins"][0] and gmax[x] == o["gauge_maxs"][0] and gamp[x] == o["gauge_amps"][0], x
+    for p in ptrs + [d_in]:
+        ctx.free(p)
+    plan.close()
