@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the I/Q STFT -> RGBA hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3|cfg4|cfg5] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path (sp_plan_execute: frame-loop kernel + the two finish kernels) over one capture of
+synthetic I/Q that is already resident in HBM, producing the RGBA image, both histograms, the gauges and the dBfs range
+in HBM.  Default workload = BASELINE.json configs[1]: 16 MSample (2^24) cf32, n = 1024, Blackman-Harris, viridis,
+gain 6, range 30, spectrogram layout, W = S/n = 16384 frames.  With N > 1 (launched by torch.distributed.run, one rank
+per GPU) every rank renders its own contiguous time slice of an N-times longer capture (weak scaling, the reference's
+own slice scheme, lib/spectroplot.js:1206-1228) and the per-slice histograms / dBfs range are combined with RCCL
+all-reduces inside the timed region; the RGBA strips stay resident on their GPUs (see DESIGN.md "Multi-GPU") and the
+gather of the strips to rank 0 is timed separately and reported as extra fields.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GEN = dict(seed=0x5EED0001, step=7321, gshift=11, amp=0.5, namp=0.02)   # trinoise, tests/siggen.py
+
+CONFIGS = {
+    # name: format, log2(samples per GPU), n, window, cmap, frames (None = S/n), description
+    "cfg1": ("CU8", 20, 512, "hann", "cube1", None, "1 MSample cu8, N=512, Hann, Cube1"),
+    "cfg2": ("CF32", 24, 1024, "blackmanHarris", "viridis", None, "16 MSample cf32, N=1024, Blackman-Harris, Viridis"),
+    "cfg3": ("CS16", 28, 2048, "hann", "cube1", None, "256 MSample cs16, N=2048, Hann, Cube1"),
+    "cfg4": ("CU8", 28, 1024, "blackmanHarris", "cube1", None, "256 MSample cu8 slice (1/8 of 2 GSample), N=1024, Blackman-Harris, Cube1"),
+    "cfg5": ("CS12", 26, 8192, "blackmanHarris", "cube1", (1 << 26) // 8192 * 8, "64 MSample cs12, N=8192, zoom x8, Blackman-Harris, Cube1"),
+}
+SAMPLE_WIDTH = {"CU8": 2, "CF32": 8, "CS16": 4, "CS12": 3}
+
+
+def load_cmap(name):
+    import numpy as np
+    idx = json.load(open(os.path.join(ROOT, "tests", "golden", "cmaps.json")))
+    blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "cmaps.bin"), dtype=np.uint8)
+    e = [x for x in idx if x["name"] == name + "_cmap"][0]
+    lut = blob[e["offset"]:e["offset"] + 3 * e["length"]].reshape(-1, 3).copy()
+    lut[0] = (0, 0, 0)            # the caller's end forcing, lib/spectroplot.js:1129-1130
+    lut[-1] = (255, 255, 255)
+    return lut
+
+
+def cpu_baseline(fmt, n, window, seconds=12.0):
+    """Times the JavaScript oracle (bit-exact restatement of the reference worker, incl. its fft_nayuki radix-2 loop) under
+    Node on this host, single thread, on a bounded sample of the same workload."""
+    script = os.path.join(ROOT, "oracle", "js", "cpu_baseline.js")
+    log2_s = 22
+    try:
+        out = subprocess.run(["node", script, fmt, str(log2_s), str(n), window, str(seconds)], capture_output=True, text=True, timeout=300)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        return {"value": r["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%s: 2^%d samples of the same synthetic %s signal, n=%d, %s, %d renders in %.1f s, node %s, 1 thread of %d host cores"
+                          % ("oracle/js/worker_oracle.js", log2_s, fmt, n, window, r["reps"], r["seconds"], r["node"], os.cpu_count()),
+                "msamples_per_s": r["msamples_per_s"]}
+    except Exception as e:  # the baseline is reported, never required
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the RGBA strips to rank 0")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    fmt, lg, n, window, cmap, frames, desc = CONFIGS[args.config]
+    S = 1 << lg
+    sw = SAMPLE_WIDTH[fmt]
+    W = frames if frames else S // n
+    dev = torch.device("cuda", local_rank)
+
+    ctx = pkg.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    win, weight = pkg.window(window, n)
+    lut = load_cmap(cmap)
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+
+    # operands resident in HBM
+    d_in = torch.empty(S * sw, dtype=torch.uint8, device=dev)
+    ctx.synth_trinoise(d_in.data_ptr(), fmt, rank * S, S, GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])
+    rgba = torch.empty(4 * W * n, dtype=torch.uint8, device=dev)
+    gauges = torch.empty(3 * W, dtype=torch.uint8, device=dev)
+    hists = torch.zeros(len(lut) + 1000, dtype=torch.int64, device=dev)
+    minmax = torch.zeros(2, dtype=torch.float64, device=dev)
+    neg = torch.tensor([-1.0, 1.0], dtype=torch.float64, device=dev)
+
+    def step():
+        hists.zero_()
+        plan.execute(d_in.data_ptr(), S * sw, W, rgba.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                     hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
+        if dist is not None:
+            # the caller's merge of the side outputs (lib/spectroplot.js:1229-1238): sums and min / max
+            dist.all_reduce(hists, op=dist.ReduceOp.SUM)
+            mm = minmax * neg                  # (-min, max) so that one MAX all-reduce serves both
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+            minmax.copy_(mm * neg)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: live HIP-event timing of the frame-loop kernel on its stream, outside the timed region
+    ctx.enable_timing(True)
+    kms = []
+    for _ in range(max(10, min(args.steps, 50))):
+        hists.zero_()
+        plan.execute(d_in.data_ptr(), S * sw, W, rgba.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                     hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
+        torch.cuda.synchronize()
+        kms.append(ctx.last_kernel_ms())
+    ctx.enable_timing(False)
+    kernel_ms = float(np.mean(kms))
+
+    gather_ms = None
+    if dist is not None and args.gather:
+        strips = [torch.empty_like(rgba) for _ in range(world)] if rank == 0 else None
+        sync()
+        g0 = time.perf_counter()
+        dist.gather(rgba, strips, dst=0)
+        sync()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    stride_eff = min((S - n) / (W - 1), n)
+    bytes_per_frame = sw * stride_eff + 4 * n + 3                 # unique input bytes + RGBA + 3 gauge bytes
+    algo_bytes = bytes_per_frame * W
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    frames_per_s = world * W * args.steps / dt
+    hsum = int(hists[:len(lut)].sum().item())
+
+    if rank == 0:
+        out = {
+            "metric": "STFT frames/sec (N=1024 cf32) + IQ MSamples/s end-to-end to RGBA" if args.config == "cfg2"
+                      else "STFT frames/sec (%s)" % desc,
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W, "format": fmt, "n": n,
+                       "samples_per_gpu": S, "frames_per_gpu": W, "window": window, "cmap": cmap,
+                       "sharding": "contiguous time slice per GPU" if world > 1 else "single GPU",
+                       "generator": "trinoise seed=0x%08X step=%d gshift=%d amp=%g namp=%g" % (GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])},
+            "msamples_per_s": frames_per_s * stride_eff / 1e6,
+            "kernel": plan.kernel_name(),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
+                         "frac_of_copy_ceiling_6290": achieved / 6290.0},
+            "checks": {"c_hist_sum": hsum, "expected": world * W * n},
+        }
+        if gather_ms is not None:
+            out["rgba_gather_ms"] = gather_ms
+            out["rgba_gather_GBps"] = (world - 1) * rgba.numel() / (gather_ms * 1e-3) / 1e9
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fmt, n, window)
+        print(json.dumps(out))
+    plan.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
