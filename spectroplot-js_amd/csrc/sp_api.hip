@@ -438,18 +438,24 @@ extern "C" void sp_plan_destroy(sp_plan *plan)
     delete plan;
 }
 
-extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
+static bool plan_lds_capable(const sp_plan *plan)
 {
-    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
-    if (which == 2 && !spk::lds_kernel_supports(plan->req.n)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this n");
-    plan->force_kernel = which;
-    return SP_OK;
+    return spk::lds_kernel_supports(plan->req.n) && plan->req.lut_len >= 2 && plan->req.lut_len <= spk::kLdsMaxLut
+           && plan->gray_b <= spk::kLdsMaxGrayB;
 }
 
 static bool plan_uses_lds(const sp_plan *plan)
 {
     if (plan->force_kernel == 1) return false;
-    return spk::lds_kernel_supports(plan->req.n);
+    return plan_lds_capable(plan);
+}
+
+extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
+{
+    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
+    if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this request");
+    plan->force_kernel = which;
+    return SP_OK;
 }
 
 extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
@@ -516,6 +522,7 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.lut_len = plan->req.lut_len;
     a.in_bounds = in_bounds ? 1 : 0;
     a.frame0 = 0;
+    a.sample_width = f.width;
     a.window = plan->d_window;
     a.cos_t = plan->d_cos;
     a.sin_t = plan->d_sin;

@@ -144,13 +144,13 @@ SP_HD inline void sample_fast(const uint8_t *p, int64_t pos, double &vi, double 
             vq = ((double)w3 / 2147483648.0 + (double)w2 / 18446744073709551616.0) - f.bias;
         }
     } else if constexpr (FMT == SP_FMT_CU8) {
-        const uint8_t *q = p + 2 * pos;
-        vi = ((double)q[0] - f.bias) * f.scale;
-        vq = ((double)q[1] - f.bias) * f.scale;
+        const uint32_t w = load_as<uint16_t>(p + 2 * pos);
+        vi = ((double)(w & 0xff) - f.bias) * f.scale;
+        vq = ((double)(w >> 8) - f.bias) * f.scale;
     } else if constexpr (FMT == SP_FMT_CS8) {
-        const uint8_t *q = p + 2 * pos;
-        vi = (double)(int8_t)q[0] * f.scale;
-        vq = (double)(int8_t)q[1] * f.scale;
+        const uint32_t w = load_as<uint16_t>(p + 2 * pos);
+        vi = (double)(int8_t)(w & 0xff) * f.scale;
+        vq = (double)(int8_t)(w >> 8) * f.scale;
     } else if constexpr (FMT == SP_FMT_CU16) {
         const uint32_t w = load_as<uint32_t>(p + 4 * pos);
         vi = ((double)(w & 0xffff) - f.bias) * f.scale;
@@ -160,21 +160,23 @@ SP_HD inline void sample_fast(const uint8_t *p, int64_t pos, double &vi, double 
         vi = (double)(int16_t)(w & 0xffff) * f.scale;
         vq = (double)(int16_t)(w >> 16) * f.scale;
     } else if constexpr (FMT == SP_FMT_CU32) {
-        const uint8_t *q = p + 8 * pos;
-        vi = ((double)load_as<uint32_t>(q) - f.bias) * f.scale;
-        vq = ((double)load_as<uint32_t>(q + 4) - f.bias) * f.scale;
+        const uint64_t w = load_as<uint64_t>(p + 8 * pos);
+        vi = ((double)(uint32_t)w - f.bias) * f.scale;
+        vq = ((double)(uint32_t)(w >> 32) - f.bias) * f.scale;
     } else if constexpr (FMT == SP_FMT_CS32) {
-        const uint8_t *q = p + 8 * pos;
-        vi = (double)load_as<int32_t>(q) * f.scale;
-        vq = (double)load_as<int32_t>(q + 4) * f.scale;
+        const uint64_t w = load_as<uint64_t>(p + 8 * pos);
+        vi = (double)(int32_t)(uint32_t)w * f.scale;
+        vq = (double)(int32_t)(uint32_t)(w >> 32) * f.scale;
     } else if constexpr (FMT == SP_FMT_CF32) {
-        const uint8_t *q = p + 8 * pos;
-        vi = (double)load_as<float>(q);
-        vq = (double)load_as<float>(q + 4);
+        struct F2 { float x, y; };
+        const F2 w = load_as<F2>(p + 8 * pos);
+        vi = (double)w.x;
+        vq = (double)w.y;
     } else {
-        const uint8_t *q = p + 16 * pos;
-        vi = load_as<double>(q);
-        vq = load_as<double>(q + 8);
+        struct D2 { double x, y; };
+        const D2 w = load_as<D2>(p + 16 * pos);
+        vi = w.x;
+        vq = w.y;
     }
 }
 

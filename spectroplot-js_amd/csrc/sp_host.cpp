@@ -145,9 +145,11 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
     // first guesses: dbfs = 5*log10(2)*log2(abs2) + block_norm_db + gain
     const double c = 5.0 * 0.30102999566398120;
     const double per_db = (double)lut_len / pm.range;
-    t.gray_a = (float)(pm.color_max + 0.5 + per_db * (pm.block_norm_db + pm.gain));
+    // gray  = floor(0.5 + color_max + per_db*dbfs)  -> guess floor(color_max + per_db*dbfs)   in {gray-1, gray}
+    // level = floor(999.5 + 10*rel_db) (off the edges) -> guess floor(999 + 10*rel_db)       in {level-1, level}
+    t.gray_a = (float)(pm.color_max + per_db * (pm.block_norm_db + pm.gain));
     t.gray_b = (float)(per_db * c);
-    t.cb_a = (float)((SP_CB_HIST_SIZE - 1) - 0.5 + 10.0 * pm.block_norm_db);
+    t.cb_a = (float)((SP_CB_HIST_SIZE - 1) + 10.0 * pm.block_norm_db);
     t.cb_b = (float)(10.0 * c);
     return t;
 }

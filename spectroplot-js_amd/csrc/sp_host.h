@@ -45,7 +45,7 @@ struct PixelMath {
 struct Thresholds {
     std::vector<double> gray_edge;   // [lut_len]
     std::vector<double> cb_edge;     // [1001]
-    // first-guess coefficients for the kernels: index ~= a + b * log2(abs2)
+    // first-guess coefficients for the LDS kernel: floor(a + b*log2(abs2)) is the exact index or one below it
     float gray_a, gray_b, cb_a, cb_b;
 };
 Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len);

@@ -31,7 +31,8 @@ namespace spk {
 
 constexpr int kLdsThreads = 512;
 constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
-constexpr int kLdsMaxLut = 1024;
+constexpr int kLdsMaxLut = 256;      // colour indices travel through a byte tile
+constexpr float kLdsMaxGrayB = 2000.0f;   // first-guess slope bound that keeps the one-compare correction exact
 constexpr int kTilePad = 4;   // tile row pitch = n + 4 bytes: conflict-free dword reads across 8 frame quads
 
 __host__ __device__ inline bool lds_kernel_supports(int n)
@@ -50,10 +51,19 @@ __host__ __device__ inline int lds_group_frames(int n, int want)
     return f;
 }
 
+// Stages 5..kLdsTwMaxStage keep their twiddle tables in LDS (table of stage s = entries [2^(s-1), 2^s) of stage_tw);
+// stages 1-4 have lane-uniform twiddles (scalar loads) and stages above kLdsTwMaxStage read HBM/L2.
+constexpr int kLdsTwMaxStage = 10;
+__host__ __device__ inline int lds_tw_entries(int n)
+{
+    const int top = n < (1 << kLdsTwMaxStage) ? n : (1 << kLdsTwMaxStage);
+    return top > 16 ? top - 16 : 0;
+}
+
 struct LdsLayout {
     int xch_doubles;   // exchange buffer (all frames of a round)
     int tile_bytes;
-    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, total;
+    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, off_tw, total;
 };
 
 __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_frames)
@@ -63,6 +73,7 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_fr
     l.xch_doubles = fpb * (n + n / 16);
     l.tile_bytes = group_frames * (n + kTilePad);
     int o = l.xch_doubles * 8;
+    l.off_tw = o;     o += lds_tw_entries(n) * 16;     // per-stage twiddles of stages 5..10 (16-byte aligned)
     l.off_gedge = o;  o += lut_len * 8;
     l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
     l.off_mm = o;     o += group_frames * 8 * 2 * 8;   // up to 8 wave partials per frame, {min,max}
@@ -79,10 +90,15 @@ __device__ inline constexpr int rev4(int e) { return ((e & 1) << 3) | ((e & 2) <
 // position owned by (thread tl, register e) under window start ws
 __device__ inline int win_pos(int tl, int e, int ws) { return (tl & ((1 << ws) - 1)) | (e << ws) | ((tl >> ws) << (ws + 4)); }
 __device__ inline int pad_idx(int p) { return p + (p >> 4); }
+// pad_idx(win_pos(tl, e, ws)) == pad_idx(win_pos(tl, 0, ws)) + win_off(e, ws): the per-register part is a compile-time
+// constant, so every LDS access of an exchange is one base register plus an immediate offset
+__device__ inline constexpr int win_off(int e, int ws) { return (e << ws) + ((e << ws) >> 4); }
 
 // One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
+// tw_lds: LDS copy of stage_tw[16 ..), tw_glb: the full table in HBM/L2.
 template <int WS, int S0, int S1>
-__device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ stage_tw)
+__device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ tw_lds,
+                                const double2 *__restrict__ tw_glb)
 {
 #pragma unroll
     for (int s = S0; s <= S1; s++) {
@@ -95,7 +111,7 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, cons
             const int e1 = e0 | (1 << u);
             // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
             const int m = tl_low | ((e0 & ((1 << u) - 1)) << WS);
-            const double2 w = stage_tw[half + m];
+            const double2 w = (s >= 5 && s <= kLdsTwMaxStage) ? tw_lds[half - 16 + m] : tw_glb[half + m];
             const double c = w.x, sn = w.y;
             const double rl = re[e1], il = im[e1];
             const double tpre = rl * c + il * sn;          // fft_nayuki.js:80
@@ -123,15 +139,16 @@ __device__ inline void frame_sync()
 }
 
 // Re-distribute the 16 values of every thread from window WS_FROM to window WS_TO through the frame's LDS buffer.
+// from / to point at this thread's element 0 under the respective window.
 template <int WS_FROM, int WS_TO, bool BLOCK_SYNC>
-__device__ inline void exchange(double (&v)[16], int tl, double *__restrict__ buf)
+__device__ inline void exchange(double (&v)[16], double *__restrict__ from, const double *__restrict__ to)
 {
-    frame_sync<BLOCK_SYNC>();   // previous readers are done with buf
+    frame_sync<BLOCK_SYNC>();   // previous readers are done with the buffer
 #pragma unroll
-    for (int e = 0; e < 16; e++) buf[pad_idx(win_pos(tl, e, WS_FROM))] = v[e];
+    for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
     frame_sync<BLOCK_SYNC>();
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = buf[pad_idx(win_pos(tl, e, WS_TO))];
+    for (int e = 0; e < 16; e++) v[e] = to[win_off(e, WS_TO)];
 }
 
 template <int FMT>
@@ -139,22 +156,35 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
                                   const double (&win)[16], double (&re)[16], double (&im)[16])
 {
     const int sidx = (int)(__brev((unsigned)tl) >> (32 - (levels - 4)));   // rev_{L-4}(tl)
+    if (a.in_bounds) {
+        // 16 independent loads issued back to back, decoded afterwards
+        double vi[16], vq[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int64_t pos = start + rev4(e) * T + sidx;
-        double vi, vq;
-        if (a.in_bounds) {
-            spfmt::sample_fast<FMT>(a.bytes, pos, vi, vq);
-        } else {
-            vi = spfmt::sample_checked<FMT>(view, pos, 0);
-            vq = spfmt::sample_checked<FMT>(view, pos, 1);
+        for (int e = 0; e < 16; e++) spfmt::sample_fast<FMT>(a.bytes, start + rev4(e) * T + sidx, vi[e], vq[e]);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            re[e] = win[e] * vi[e];                                            // worker.js:73-74
+            im[e] = win[e] * vq[e];
         }
-        re[e] = win[e] * vi;                                                   // worker.js:73-74
-        im[e] = win[e] * vq;
+    } else {
+#pragma unroll 1
+        for (int e = 0; e < 16; e++) {
+            const int64_t pos = start + rev4(e) * T + sidx;
+            // runtime register index: keep this rare path small (it is only taken when frames leave the buffer)
+            const double vi = spfmt::sample_checked<FMT>(view, pos, 0);
+            const double vq = spfmt::sample_checked<FMT>(view, pos, 1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k == e) {
+                    re[k] = win[k] * vi;
+                    im[k] = win[k] * vq;
+                }
+            }
+        }
     }
 }
 
-template <int LOG2N>
+template <int LOG2N, bool CH>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                          const int group_frames, const int groups)
 {
@@ -168,6 +198,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
     double *s_xch = (double *)smem;
+    double2 *s_tw = (double2 *)(smem + lay.off_tw);
     double *s_gedge = (double *)(smem + lay.off_gedge);
     double *s_cbedge = (double *)(smem + lay.off_cbedge);
     double *s_mm = (double *)(smem + lay.off_mm);
@@ -189,6 +220,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         s_chist[i] = 0;
     }
     for (int i = tid; i <= SP_CB_HIST_SIZE; i += kLdsThreads) s_cbedge[i] = a.cb_edge[i];
+    for (int i = tid; i < lds_tw_entries(N); i += kLdsThreads) s_tw[i] = stage_tw[16 + i];
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads) s_cbhist[i] = 0;
 
     // taper coefficients of this thread's 16 samples stay in registers for the whole launch
@@ -201,8 +233,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     __syncthreads();
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
-    // clipped colour indices and the last centi-bel bin are counted in registers (they dominate typical images)
+    uint32_t pf_word = 0;
+    // clipped colour indices and the end bins of the centi-bel histogram are counted per wave in scalar registers
+    // (they dominate typical images and would serialise as same-address LDS atomics)
     unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
+    const float gray_a = a.gray_a, gray_b = a.gray_b, cb_a = a.cb_a, cb_b = a.cb_b;
+    const float c_hi = (float)(cmax - 1);
 
     // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
     const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -218,6 +254,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             const int x = live ? xr : a.width - 1;  // surplus slots recompute the last frame and discard it
             const int64_t start = frame_start(a.stride, x);
 
+            // Touch the cache lines of the frame this slot processes next, so that its loads hit L2 instead of HBM.
+            asm volatile("" ::"v"(pf_word));   // the previous touch has long landed; this only keeps the load alive
+            if (a.in_bounds) {
+                const int xn = (r + 1 < group_frames / FPB) ? xr + FPB : (g + per_xcd) * group_frames + fs;
+                const int lines = (N * a.sample_width + 127) >> 7;
+                if (xn < a.width) {
+                    const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
+                    for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
+                }
+            }
+
             double re[16], im[16];
             switch (format) {
 #define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im); break;
@@ -229,30 +276,38 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
 
             // ---- DFT: register passes with LDS re-distribution in between ---------------------------------
-            fft_pass<0, 1, 4>(re, im, tl, stage_tw);
+            // Twiddles above stage 10 are re-read every frame (L2 hits, consecutive across lanes); hiding the offset from
+            // the optimiser keeps it from hoisting loop-invariant twiddle registers out of the frame loop.
+            unsigned tw_off = 0;
+            asm volatile("" : "+s"(tw_off));
+            const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
+            fft_pass<0, 1, 4>(re, im, tl, s_tw, stage_tw);
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
-                exchange<0, WS1, BLOCK_SYNC>(re, tl, xbuf);
-                exchange<0, WS1, BLOCK_SYNC>(im, tl, xbuf);
-                fft_pass<WS1, 5, E1>(re, im, tl, stage_tw);
+                double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
+                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
+                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                fft_pass<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
-                    exchange<WS1, WS2, BLOCK_SYNC>(re, tl, xbuf);
-                    exchange<WS1, WS2, BLOCK_SYNC>(im, tl, xbuf);
-                    fft_pass<WS2, 9, E2>(re, im, tl, stage_tw);
+                    double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
+                    exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
+                    exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                    fft_pass<WS2, 9, E2>(re, im, tl, s_tw, tw);
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
-                        exchange<WS2, WS3, BLOCK_SYNC>(re, tl, xbuf);
-                        exchange<WS2, WS3, BLOCK_SYNC>(im, tl, xbuf);
-                        fft_pass<WS3, 13, LOG2N>(re, im, tl, stage_tw);
+                        double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
+                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
+                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
+                        fft_pass<WS3, 13, LOG2N>(re, im, tl, s_tw, tw);
                     }
                 }
             }
             // now register e of thread tl holds bin i = tl + e*T
 
-            if (a.channel_mode) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
+            if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
                 double pr[16], pi[16];
                 frame_sync<BLOCK_SYNC>();
 #pragma unroll
@@ -286,41 +341,43 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
 
             // ---- |X|^2 -> indices ---------------------------------------------------------------------------
+            // The first guess floor(a + b*log2(abs2)) is biased half a step low, so the exact index is the guess or
+            // the guess + 1; one comparison against the exact edge decides (edges: sp_host.h Thresholds).
             double mn = spjs::inf(), mx = 0.0;
             unsigned char *trow = s_tile + fr * tile_pitch;
+            double abs2[16];
+            int gc[16], lc[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const double abs2 = re[e] * re[e] + im[e] * im[e];                 // worker.js:92
-                mn = min_nn(mn, abs2);
-                mx = max_nn(mx, abs2);
-                // first guess from the hardware log2 on the mantissa, exact result from the edge tables
+                abs2[e] = re[e] * re[e] + im[e] * im[e];                           // worker.js:92
+                mn = min_nn(mn, abs2[e]);
+                mx = max_nn(mx, abs2[e]);
                 int ex;
-                const double mant = frexp(abs2, &ex);
+                const double mant = frexp(abs2[e], &ex);
                 const float l2 = (float)ex + __log2f((float)mant);
-                int gr = (int)fminf(fmaxf(floorf(a.gray_a + a.gray_b * l2), 0.0f), (float)cmax);
-                while (gr < cmax && abs2 >= s_gedge[gr + 1]) gr++;
-                while (gr > 0 && !(abs2 >= s_gedge[gr])) gr--;
-                int bin;
-                if (!(abs2 > 0.0) || abs2 == spjs::inf()) {
-                    bin = 0;
-                } else {
-                    int lv = (int)fminf(fmaxf(floorf(a.cb_a + a.cb_b * l2), 0.0f), (float)SP_CB_HIST_SIZE);
-                    while (lv < SP_CB_HIST_SIZE && abs2 >= s_cbedge[lv + 1]) lv++;
-                    while (lv > 0 && !(abs2 >= s_cbedge[lv])) lv--;
-                    bin = SP_CB_HIST_SIZE - 1 - lv;
-                }
-                if (cmax < 256) trow[tl + e * T] = (unsigned char)gr;
+                gc[e] = (int)fminf(fmaxf(floorf(fmaf(gray_b, l2, gray_a)), 0.0f), c_hi);
+                lc[e] = (int)fminf(fmaxf(floorf(fmaf(cb_b, l2, cb_a)), 0.0f), (float)(SP_CB_HIST_SIZE - 1));
+            }
+            double ge[16], ce[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                ge[e] = s_gedge[gc[e] + 1];
+                ce[e] = s_cbedge[lc[e] + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int gr = gc[e] + (abs2[e] >= ge[e] ? 1 : 0);
+                const int lv = lc[e] + (abs2[e] >= ce[e] ? 1 : 0);
+                // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0                worker.js:105
+                const bool special = !(abs2[e] > 0.0) || abs2[e] == spjs::inf();
+                trow[tl + e * T] = (unsigned char)gr;
                 if (live) {
-                    if (gr == 0) cnt_g0++;
-                    else if (gr == cmax) cnt_gmax++;
-                    else atomicAdd(&s_chist[gr], 1u);
-                    if (bin == SP_CB_HIST_SIZE - 1) cnt_cb_last++;
-                    else if (bin == 0) cnt_cb0++;
-                    else if (bin > 0) atomicAdd(&s_cbhist[bin], 1u);
-                }
-                if (cmax >= 256) {
-                    // colour maps longer than 256 entries do not fit the byte tile: store the pixel directly
-                    if (live && a.rgba) *(uint32_t *)(a.rgba + pixel_offset(N, a.width, a.waterfall, x, tl + e * T)) = s_lut[gr];
+                    cnt_g0 += (unsigned int)__popcll(__ballot(gr == 0));
+                    cnt_gmax += (unsigned int)__popcll(__ballot(gr == cmax));
+                    if (gr != 0 && gr != cmax) atomicAdd(&s_chist[gr], 1u);
+                    cnt_cb0 += (unsigned int)__popcll(__ballot(special));
+                    cnt_cb_last += (unsigned int)__popcll(__ballot(!special && lv == 0));
+                    if (!special && lv != 0 && lv != SP_CB_HIST_SIZE) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
                 }
             }
             // frame min / max over its T threads
@@ -356,7 +413,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         }
 
         // ---- tile -> RGBA -------------------------------------------------------------------------------------
-        if (a.rgba && cmax < 256) {
+        if (a.rgba) {
             if (!a.waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
                 // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
@@ -407,10 +464,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     }
 
     // ---- flush histograms ----------------------------------------------------------------------------------------
-    if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
-    if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
-    if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
-    if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
+    if ((tid & 63) == 0) {   // the ballot counters are per wave
+        if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
+        if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
+        if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
+        if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
+    }
     __syncthreads();
     for (int i = tid; i < a.lut_len; i += kLdsThreads)
         if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
@@ -421,7 +480,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 // Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
 inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, hipStream_t stream)
 {
-    if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut) return SP_ERR_UNSUPPORTED;
+    if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut || a.lut_len < 2 || !(a.gray_b <= kLdsMaxGrayB)) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
     // tile height: 32 frames give 128-byte row segments; small images use shorter groups so every CU gets work
     int want = 32;
@@ -432,24 +491,28 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;
 
-#define SP_LAUNCH(L)                                                                                                     \
-    case L: {                                                                                                            \
+#define SP_LAUNCH_CH(L, C)                                                                                               \
+    {                                                                                                                    \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            if (hipFuncSetAttribute((const void *)k_lds_r16<L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)   \
+            if (hipFuncSetAttribute((const void *)k_lds_r16<L, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) \
                 != hipSuccess)                                                                                           \
                 return SP_ERR_HIP;                                                                                       \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL(k_lds_r16<L>, dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a, format, \
-                           stage_tw, gf, groups);                                                                        \
-        break;                                                                                                           \
+        hipLaunchKernelGGL((k_lds_r16<L, C>), dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a,     \
+                           format, stage_tw, gf, groups);                                                                \
     }
+#define SP_LAUNCH(L)                                                                                                     \
+    case L:                                                                                                              \
+        if (a.channel_mode) SP_LAUNCH_CH(L, true) else SP_LAUNCH_CH(L, false)                                            \
+        break;
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
     switch (a.levels) {
         SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8) SP_LAUNCH(9) SP_LAUNCH(10) SP_LAUNCH(11) SP_LAUNCH(12) SP_LAUNCH(13)
     default: return SP_ERR_UNSUPPORTED;
     }
+#undef SP_LAUNCH_CH
 #undef SP_LAUNCH
     return SP_OK;
 }
