@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the RGBA strips to rank 0")
+    ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
+    ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,12 +107,13 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     win, weight = pkg.window(window, n)
     lut = load_cmap(cmap)
-    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, waterfall=args.waterfall)
 
     # operands resident in HBM
     d_in = torch.empty(S * sw, dtype=torch.uint8, device=dev)
     ctx.synth_trinoise(d_in.data_ptr(), fmt, rank * S, S, GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])
     rgba = torch.empty(4 * W * n, dtype=torch.uint8, device=dev)
+    rgba_ptr = 0 if args.no_rgba else rgba.data_ptr()
     gauges = torch.empty(3 * W, dtype=torch.uint8, device=dev)
     hists = torch.zeros(len(lut) + 1000, dtype=torch.int64, device=dev)
     minmax = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -118,7 +121,7 @@ def main():
 
     def step():
         hists.zero_()
-        plan.execute(d_in.data_ptr(), S * sw, W, rgba.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+        plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
         if dist is not None:
             # the caller's merge of the side outputs (lib/spectroplot.js:1229-1238): sums and min / max
@@ -150,7 +153,7 @@ def main():
     kms = []
     for _ in range(max(10, min(args.steps, 50))):
         hists.zero_()
-        plan.execute(d_in.data_ptr(), S * sw, W, rgba.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+        plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
         torch.cuda.synchronize()
         kms.append(ctx.last_kernel_ms())

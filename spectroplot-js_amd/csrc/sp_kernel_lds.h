@@ -63,7 +63,7 @@ __host__ __device__ inline int lds_tw_entries(int n)
 struct LdsLayout {
     int xch_doubles;   // exchange buffer (all frames of a round)
     int tile_bytes;
-    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, off_tw, total;
+    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, off_tw, off_trash, total;
 };
 
 __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_frames)
@@ -81,8 +81,17 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_fr
     l.off_lut = o;    o += lut_len * 4;
     l.off_chist = o;  o += lut_len * 4;
     l.off_cbhist = o; o += SP_CB_HIST_SIZE * 4;
+    l.off_trash = o;  o += kLdsThreads * 4;
     l.total = (o + 15) & ~15;
     return l;
+}
+
+// floor(x) as int32 in one instruction (callers clamp first; a NaN input does not give 0 on gfx950)
+__device__ inline int floor_to_int(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 __device__ inline constexpr int rev4(int e) { return ((e & 1) << 3) | ((e & 2) << 1) | ((e & 4) >> 1) | ((e & 8) >> 3); }
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
     unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);
     unsigned int *s_cbhist = (unsigned int *)(smem + lay.off_cbhist);
+    unsigned int *const trash = (unsigned int *)(smem + lay.off_trash) + threadIdx.x;
 
     const int tid = threadIdx.x;
     const int fs = tid / T;                         // frame slot within a round
@@ -234,11 +244,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
-    // clipped colour indices and the end bins of the centi-bel histogram are counted per wave in scalar registers
+    // clipped colour indices and the end bins of the centi-bel histogram are counted in per-lane registers
     // (they dominate typical images and would serialise as same-address LDS atomics)
     unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
     const float gray_a = a.gray_a, gray_b = a.gray_b, cb_a = a.cb_a, cb_b = a.cb_b;
-    const float c_hi = (float)(cmax - 1);
+    const float gc_hi = (float)(cmax - 1);
 
     // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
     const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -355,8 +365,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 int ex;
                 const double mant = frexp(abs2[e], &ex);
                 const float l2 = (float)ex + __log2f((float)mant);
-                gc[e] = (int)fminf(fmaxf(floorf(fmaf(gray_b, l2, gray_a)), 0.0f), c_hi);
-                lc[e] = (int)fminf(fmaxf(floorf(fmaf(cb_b, l2, cb_a)), 0.0f), (float)(SP_CB_HIST_SIZE - 1));
+                // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
+                gc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
+                lc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
             }
             double ge[16], ce[16];
 #pragma unroll
@@ -364,6 +375,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 ge[e] = s_gedge[gc[e] + 1];
                 ce[e] = s_cbedge[lc[e] + 1];
             }
+            // Histograms without branches: values that are counted in per-lane registers (clipped colour indices, the end
+            // bins of the centi-bel histogram) and values that are not counted at all (surplus frames, dropped keys) send
+            // their LDS atomic to a per-lane trash word instead of serialising on one hot address.
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int gr = gc[e] + (abs2[e] >= ge[e] ? 1 : 0);
@@ -371,14 +385,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0                worker.js:105
                 const bool special = !(abs2[e] > 0.0) || abs2[e] == spjs::inf();
                 trow[tl + e * T] = (unsigned char)gr;
-                if (live) {
-                    cnt_g0 += (unsigned int)__popcll(__ballot(gr == 0));
-                    cnt_gmax += (unsigned int)__popcll(__ballot(gr == cmax));
-                    if (gr != 0 && gr != cmax) atomicAdd(&s_chist[gr], 1u);
-                    cnt_cb0 += (unsigned int)__popcll(__ballot(special));
-                    cnt_cb_last += (unsigned int)__popcll(__ballot(!special && lv == 0));
-                    if (!special && lv != 0 && lv != SP_CB_HIST_SIZE) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
-                }
+                const bool g0 = gr == 0, gm = gr == cmax;
+                cnt_g0 += (live && g0) ? 1u : 0u;
+                cnt_gmax += (live && gm) ? 1u : 0u;
+                atomicAdd((g0 || gm || !live) ? trash : &s_chist[gr], 1u);
+                const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
+                cnt_cb0 += (live && special) ? 1u : 0u;
+                cnt_cb_last += (live && !special && l0) ? 1u : 0u;
+                atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
             }
             // frame min / max over its T threads
 #pragma unroll
@@ -464,12 +478,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     }
 
     // ---- flush histograms ----------------------------------------------------------------------------------------
-    if ((tid & 63) == 0) {   // the ballot counters are per wave
-        if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
-        if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
-        if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
-        if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
-    }
+    if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);          // per-lane counters of the clipped / end bins
+    if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
+    if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
+    if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
     __syncthreads();
     for (int i = tid; i < a.lut_len; i += kLdsThreads)
         if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
