@@ -136,9 +136,9 @@ void sp_plan_destroy(sp_plan *plan);
  * Histograms are accumulated into reply->c_hist / cb_hist.
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
-/* Name of the kernel variant sp_plan_execute would launch for this width ("lds_r16", "scratch_radix2", ...). */
+/* Name of the kernel variant sp_plan_execute launches ("wave_r16+colorize", "lds_r16", "scratch_radix2"). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
-/* Forces the portable scratch-memory kernel (tests compare the two device paths). 0 = automatic. */
+/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16, 3 wave_r16. */
 int sp_plan_force_kernel(sp_plan *plan, int32_t which);
 
 /* Device memory helpers so that non-HIP hosts (Node, ctypes) can keep operands resident. */

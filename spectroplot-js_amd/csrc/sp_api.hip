@@ -16,6 +16,7 @@
 #include "../../include/spectroplot_hip.h"
 #include "sp_host.h"
 #include "sp_kernel_lds.h"
+#include "sp_kernel_wave.h"
 #include "sp_kernel_scratch.h"
 #include "sp_synth.h"
 
@@ -58,6 +59,7 @@ struct sp_context {
     DeviceBuffer frame_minmax;   // 2 * width doubles
     DeviceBuffer partial;        // finish-kernel partials
     DeviceBuffer scratch;        // scratch kernel slabs
+    DeviceBuffer gray;           // colour-index plane between k_wave_r16 and k_colorize (one cache-resident chunk)
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small, hist_dummy;
     sp_plan *cached_plan = nullptr;
@@ -80,7 +82,7 @@ struct sp_plan {
     const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
     const uint32_t *d_lut = nullptr;
     const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
-    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds
+    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds, 3 wave
 };
 
 namespace {
@@ -234,6 +236,7 @@ extern "C" void sp_context_destroy(sp_context *ctx)
     ctx->frame_minmax.release();
     ctx->partial.release();
     ctx->scratch.release();
+    ctx->gray.release();
     ctx->in_bytes.release();
     ctx->out_rgba.release();
     ctx->render_small.release();
@@ -444,16 +447,23 @@ static bool plan_lds_capable(const sp_plan *plan)
            && plan->gray_b <= spk::kLdsMaxGrayB;
 }
 
-static bool plan_uses_lds(const sp_plan *plan)
+static bool plan_wave_capable(const sp_plan *plan) { return plan_lds_capable(plan) && spk::wave_kernel_supports(plan->req.n); }
+
+// 1 = scratch_radix2, 2 = lds_r16, 3 = wave_r16 + colorize
+static int plan_kernel(const sp_plan *plan)
 {
-    if (plan->force_kernel == 1) return false;
-    return plan_lds_capable(plan);
+    if (plan->force_kernel) return plan->force_kernel;
+    // The fused LDS kernel is the default.  The two-kernel variant (3) measured no faster on MI355X (its extra waves
+    // are spent on LDS / f64 issue contention, DESIGN.md "What was tried"); it stays selectable for comparison.
+    if (plan_lds_capable(plan)) return 2;
+    return 1;
 }
 
 extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
 {
-    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
+    if (!plan || which < 0 || which > 3) return SP_ERR_INVALID_ARG;
     if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this request");
+    if (which == 3 && !plan_wave_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "wave kernel does not cover this request");
     plan->force_kernel = which;
     return SP_OK;
 }
@@ -461,7 +471,11 @@ extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
 extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 {
     if (!plan) return "";
-    return plan_uses_lds(plan) ? "lds_r16" : "scratch_radix2";
+    switch (plan_kernel(plan)) {
+    case 3: return "wave_r16+colorize";
+    case 2: return "lds_r16";
+    default: return "scratch_radix2";
+    }
 }
 
 extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *out)
@@ -523,6 +537,10 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.in_bounds = in_bounds ? 1 : 0;
     a.frame0 = 0;
     a.sample_width = f.width;
+    {
+        static const int dbg_flags = getenv("SP_DEBUG_FLAGS") ? atoi(getenv("SP_DEBUG_FLAGS")) : 0;   // profiling ablations only
+        a.dbg = dbg_flags;
+    }
     a.window = plan->d_window;
     a.cos_t = plan->d_cos;
     a.sin_t = plan->d_sin;
@@ -550,8 +568,21 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.c_hist = c_hist;
     a.cb_hist = cb_hist;
 
+    const int which = plan_kernel(plan);
+    if (which == 3) {
+        // colour-index plane: one chunk of at most 24 MiB, so that it is still cache resident when k_colorize reads it
+        size_t want = (size_t)width * (size_t)n;
+        const size_t cap = (size_t)24 << 20;
+        if (want > cap) want = cap;
+        want = (want + 64 * (size_t)n - 1) / (64 * (size_t)n) * (64 * (size_t)n);
+        rc = ctx->gray.reserve(want);
+        if (rc) return fail(ctx, rc, "colour-index plane: out of device memory");
+    }
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (plan_uses_lds(plan)) {
+    if (which == 3) {
+        rc = spk::launch_wave(a, plan->req.format, plan->d_stage_tw, (uint8_t *)ctx->gray.p, ctx->gray.cap, ctx->cu_count, s);
+        if (rc) return fail(ctx, rc, "wave kernel launch rejected the configuration");
+    } else if (which == 2) {
         rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
         if (rc) return fail(ctx, rc, "LDS kernel launch rejected the configuration");
     } else {

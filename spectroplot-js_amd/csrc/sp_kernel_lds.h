@@ -140,17 +140,17 @@ __device__ inline void frame_sync()
     if constexpr (BLOCK_SYNC) {
         __syncthreads();
     } else {
-        // the frame lives in one wave: LDS operations of a wave execute in order, only the compiler must not reorder
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The frame lives in one wave and the LDS executes a wave's operations in order, so the hardware needs nothing;
+        // only the compiler must not move LDS accesses across this point.  (A wavefront-scope fence is NOT used here:
+        // hipcc lowers it to s_waitcnt vmcnt(0), which would stall every exchange on the outstanding HBM loads.)
+        asm volatile("" ::: "memory");
     }
 }
 
 // Re-distribute the 16 values of every thread from window WS_FROM to window WS_TO through the frame's LDS buffer.
 // from / to point at this thread's element 0 under the respective window.
 template <int WS_FROM, int WS_TO, bool BLOCK_SYNC>
-__device__ inline void exchange(double (&v)[16], double *__restrict__ from, const double *__restrict__ to)
+__device__ inline void exchange(double (&v)[16], double *from, const double *to)   // from / to alias: no __restrict__
 {
     frame_sync<BLOCK_SYNC>();   // previous readers are done with the buffer
 #pragma unroll

@@ -18,6 +18,7 @@ struct FrameArgs {
     int32_t in_bounds;           // every frame lies inside the buffer: unchecked loads are safe
     int32_t frame0;              // first frame of this launch (always 0 today)
     int32_t sample_width;        // bytes per complex sample
+    int32_t dbg;                 // ablation switches for profiling builds (SP_DEBUG_FLAGS); 0 in production
     const double *window;        // [n]
     const double *cos_t;         // [n/2]
     const double *sin_t;         // [n/2]

@@ -82,7 +82,7 @@ def test_golden_worker_cases_sp_render(pkg, ctx, golden):
     assert not bad, bad[:30]
 
 
-@pytest.mark.parametrize("kernel", ["scratch", "lds"])
+@pytest.mark.parametrize("kernel", ["scratch", "lds", "wave"])
 def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
     """The same vectors through sp_plan_execute with each device kernel forced (device-resident operands)."""
     bad, ran = [], 0
@@ -97,7 +97,7 @@ def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
             continue   # this kernel does not cover the case's n
         ran += 1
         bad += goldenlib.check_reply(r, e["reply"], "%s[%s]: " % (c["name"], r["kernel"]))
-    assert ran > 50
+    assert ran > 40
     assert not bad, bad[:30]
 
 
