@@ -1,0 +1,110 @@
+'use strict'
+/**
+ * HipWorker — a Worker-shaped object for triq-org/spectroplot-js' `workerOrUrl` option, backed by the MI355X HIP library.
+ *
+ * The reference constructs its render workers with `new workerOrUrl()` when the option is not a URL string
+ * (lib/spectroplot.js:100-116) and only uses two members: `postMessage(message, transfer)` and an assignable
+ * `onmessage`.  This class provides exactly that, with the reference worker's contract:
+ *   - a message without a `buffer` is ignored (the transferable probe, lib/worker.js:158-163, lib/spectroplot.js:118-119);
+ *   - every render request produces exactly one reply, replies come back in request order (FIFO per instance);
+ *   - the reply has the reference's fields (lib/worker.js:140-155): cB_hist, c_hist, dBfs_min, dBfs_max, offset,
+ *     gauge_mins / gauge_maxs / gauge_amps (Uint8ClampedArray) and imageData.data (Uint8ClampedArray).
+ * Where the reference worker would throw (and leave the caller's promise pending forever), this class reports an
+ * `onerror({message, status})` event (or an 'error' listener) and still never emits a malformed reply.
+ *
+ * Instances are spread over the visible GPUs round-robin, so the reference's pool of N workers maps onto N devices
+ * (its per-worker time slices become per-GPU shards).  There is no CPU fallback.
+ */
+const path = require('path')
+
+let native = null
+function addon() {
+    if (!native) native = require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node'))
+    return native
+}
+
+let nextDevice = 0
+
+/** cmap entries -> packed Uint8Array with the store semantics of the reference's Uint8ClampedArray image (worker.js:118-121). */
+function packLut(cmap) {
+    const lut = new Uint8ClampedArray(cmap.length * 3)
+    for (let i = 0; i < cmap.length; i++) {
+        lut[3 * i] = cmap[i][0]; lut[3 * i + 1] = cmap[i][1]; lut[3 * i + 2] = cmap[i][2]
+    }
+    return new Uint8Array(lut.buffer)
+}
+
+class HipWorker {
+    /** @param {{device?: number}} [options] — device index; default: round-robin over the visible GPUs. */
+    constructor(options) {
+        this.onmessage = null
+        this.onerror = null
+        this._listeners = { message: [], error: [] }
+        this._queue = Promise.resolve()
+        this._closed = false
+        const n = addon().deviceCount()
+        if (n < 1) throw Object.assign(new Error('no HIP device: spectroplot-hip has no CPU fallback'), { status: -5 })
+        this.device = options && options.device !== undefined ? options.device : (nextDevice++ % n)
+        this._ctx = addon().createContext(this.device)
+    }
+
+    addEventListener(type, fn) { if (this._listeners[type]) this._listeners[type].push(fn) }
+    removeEventListener(type, fn) {
+        if (this._listeners[type]) this._listeners[type] = this._listeners[type].filter(f => f !== fn)
+    }
+
+    _emit(type, event) {
+        const h = type === 'message' ? this.onmessage : this.onerror
+        if (typeof h === 'function') h.call(this, event)
+        for (const fn of this._listeners[type]) fn.call(this, event)
+    }
+
+    /** Same signature as Worker.postMessage; `transfer` is accepted and ignored (the buffer is read in place). */
+    postMessage(message, transfer) { // eslint-disable-line no-unused-vars
+        if (this._closed) return
+        if (!(message && message.buffer)) return                        // worker.js:159
+        // requests are serialised per instance, like one worker thread; the GPU work itself runs off the event loop
+        this._queue = this._queue.then(() => this._render(message)).then(
+            reply => this._emit('message', { data: reply }),
+            err => this._emit('error', { message: err.message, status: err.status, error: err }))
+    }
+
+    _request(m) {
+        const a = addon()
+        const fmt = a.parseFormat(String(m.format))                     // upper-cases, aliases, unknown -> CU8
+        const n = m.n
+        const windowc = m.windowc instanceof Float64Array ? m.windowc : Float64Array.from(m.windowc)
+        let buffer = m.buffer
+        if (ArrayBuffer.isView(buffer)) buffer = buffer.buffer.slice(buffer.byteOffset, buffer.byteOffset + buffer.byteLength)
+        return { format: fmt.id, buffer, n, windowc, block_norm: m.block_norm, gain: m.gain, range: m.range,
+            lut: packLut(m.cmap), width: m.width, channelMode: !!m.channelMode, waterfall: !!m.waterfall }
+    }
+
+    _wrap(m, r) {
+        return {
+            cB_hist: Array.from(r.cB_hist), c_hist: Array.from(r.c_hist), dBfs_min: r.dBfs_min, dBfs_max: r.dBfs_max,
+            offset: m.offset,
+            gauge_mins: new Uint8ClampedArray(r.gauge_mins), gauge_maxs: new Uint8ClampedArray(r.gauge_maxs),
+            gauge_amps: new Uint8ClampedArray(r.gauge_amps), imageData: { data: new Uint8ClampedArray(r.rgba) },
+        }
+    }
+
+    _render(m) {
+        return new Promise((resolve, reject) => {
+            let req
+            try { req = this._request(m) } catch (e) { reject(e); return }
+            addon().render(this._ctx, req, (err, r) => err ? reject(err) : resolve(this._wrap(m, r)))
+        })
+    }
+
+    /** Synchronous render of one message (used by tests and by callers that drive the GPUs themselves). */
+    renderSync(m) { return this._wrap(m, addon().renderSync(this._ctx, this._request(m))) }
+
+    terminate() { this._closed = true; this._ctx = null }
+}
+
+/** A constructor bound to one device, for `workerOrUrl: HipWorker.onDevice(3)`. */
+HipWorker.onDevice = (device) => class extends HipWorker { constructor() { super({ device }) } }
+HipWorker.deviceCount = () => addon().deviceCount()
+
+module.exports = { HipWorker, packLut }

@@ -1,0 +1,5 @@
+'use strict'
+/** Node entry point: `const { HipWorker } = require('spectroplot-js_amd/js')` then `new Spectroplot({workerOrUrl: HipWorker, ...})`. */
+const { HipWorker, packLut } = require('./hip_worker.js')
+const { renderSliced } = require('./render_file.js')
+module.exports = { HipWorker, packLut, renderSliced }

@@ -1,0 +1,66 @@
+'use strict'
+/**
+ * The data half of the reference caller's processData (lib/spectroplot.js:1113-1130, :1206-1244) for Node: evaluates the
+ * taper, forces the LUT ends, cuts the capture into `workers` contiguous slices (lib/samples.js:253-258), renders each
+ * slice on its own HipWorker (= its own GPU when several are visible) and merges strips, histograms and the dBfs range.
+ * Un-rendered columns stay zero, as on the reference's canvas.
+ */
+const path = require('path')
+const { HipWorker } = require('./hip_worker.js')
+
+function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node')) }
+
+/**
+ * @param {{buffer: ArrayBuffer, format: string, n: number, width: number, workers?: number, window?: string|{window, weight},
+ *          cmap: number[][], gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean}} o
+ * @returns {Promise<{data: Uint8ClampedArray, width, height, c_hist, cB_hist, dBfs_min, dBfs_max, sliceWidth, replies}>}
+ */
+function renderSliced(o, pool) {
+    const a = native()
+    const workers = o.workers || Math.max(1, a.deviceCount())
+    const n = o.n
+    const w = typeof o.window === 'object' && o.window ? o.window : a.window(o.window || 'blackmanHarris', n)
+    const block_norm = 1.0 / w.weight                                   // spectroplot.js:1116
+    const cmap = o.cmap.map(c => c.slice())
+    cmap[0] = [0, 0, 0]; cmap[cmap.length - 1] = [255, 255, 255]     // spectroplot.js:1129-1130
+    const gain = o.gain === undefined ? 6 : o.gain, range = o.range === undefined ? 30 : o.range
+    const fmt = a.parseFormat(o.format)
+    const width = o.width, sliceWidth = ~~(width / workers)             // spectroplot.js:1208
+    const own = !pool
+    pool = pool || Array.from({ length: workers }, () => new HipWorker())
+    const merged = new Uint8ClampedArray(4 * width * n)
+    const c_hist = new Array(cmap.length).fill(0), cB_hist = new Array(1000).fill(0)
+    let dBfs_min = 0.0, dBfs_max = -200.0
+    const jobs = []
+    for (let i = 0; i < workers; i++) {
+        const [b0, b1] = a.sliceBounds(o.buffer.byteLength, fmt.sampleWidth, i, workers)
+        const message = { block_norm, gain, range, cmap, n, windowc: w.window, width: sliceWidth, offset: i * sliceWidth,
+            buffer: o.buffer.slice(b0, b1), format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+        jobs.push(new Promise((resolve, reject) => {
+            const wk = pool[i % pool.length]
+            const prevM = wk.onmessage, prevE = wk.onerror
+            wk.onmessage = (e) => { wk.onmessage = prevM; wk.onerror = prevE; resolve(e.data) }
+            wk.onerror = (e) => { wk.onmessage = prevM; wk.onerror = prevE; reject(e.error || new Error(e.message)) }
+            wk.postMessage(message, [message.buffer])
+        }))
+    }
+    return Promise.all(jobs).then(replies => {
+        for (const r of replies) {
+            if (r.dBfs_min < dBfs_min) dBfs_min = r.dBfs_min
+            if (r.dBfs_max > dBfs_max) dBfs_max = r.dBfs_max
+            for (let k = 0; k < 1000; k++) cB_hist[k] += r.cB_hist[k]
+            for (let k = 0; k < cmap.length; k++) c_hist[k] += r.c_hist[k]
+            const img = r.imageData.data
+            if (!o.waterfall) {                                          // putImageData(strip, offset, 0)
+                for (let y = 0; y < n; y++) merged.set(img.subarray(4 * y * sliceWidth, 4 * (y + 1) * sliceWidth), 4 * (y * width + r.offset))
+            } else {                                                     // putImageData(strip, 0, width - sliceWidth - offset)
+                merged.set(img, 4 * n * (width - sliceWidth - r.offset))
+            }
+        }
+        if (own) pool.forEach(wk => wk.terminate())
+        return { data: merged, width: o.waterfall ? n : width, height: o.waterfall ? width : n, c_hist, cB_hist, dBfs_min, dBfs_max,
+            sliceWidth, replies }
+    })
+}
+
+module.exports = { renderSliced }

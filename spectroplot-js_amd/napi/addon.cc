@@ -1,0 +1,383 @@
+// addon.cc — N-API binding of the C ABI (include/spectroplot_hip.h) for Node.js.
+//
+// The JavaScript class HipWorker (js/hip_worker.js) is what the reference library receives through its
+// `workerOrUrl` option (lib/spectroplot.js:100-116); this file only moves typed-array pointers across the
+// language boundary.  No compute happens here and there is no fallback: every entry point that needs a device
+// throws when the HIP library reports an error.
+//
+// Exports
+//   deviceCount()                                  -> number
+//   parseFormat(name)                              -> {id, sampleWidth}
+//   window(name, n)                                -> {window: Float64Array, weight}
+//   sliceBounds(nbytes, sampleWidth, index, count) -> [begin, end]
+//   createContext(device)                          -> external handle
+//   destroyContext(handle)
+//   render(handle, req, cb)   req = {format:int, buffer:ArrayBuffer, n, windowc:Float64Array, block_norm, gain, range,
+//                                    lut:Uint8Array, width, channelMode, waterfall}
+//       runs sp_render on a libuv worker thread and calls cb(err, {rgba, gauge_mins, gauge_maxs, gauge_amps: ArrayBuffer,
+//       c_hist, cB_hist: Float64Array, dBfs_min, dBfs_max}) on the main thread
+//   renderSync(handle, req)                        -> the same reply object, synchronously
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spectroplot_hip.h"
+
+namespace {
+
+#define NAPI_OK(env, call)                                                         \
+    do {                                                                           \
+        if ((call) != napi_ok) {                                                   \
+            napi_throw_error((env), nullptr, "N-API call failed: " #call);        \
+            return nullptr;                                                        \
+        }                                                                          \
+    } while (0)
+
+napi_value throw_status(napi_env env, int status, const char *msg)
+{
+    std::string m = (msg && *msg) ? msg : sp_status_string(status);
+    napi_value err, text, code;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &text);
+    napi_create_error(env, nullptr, text, &err);
+    napi_create_int32(env, status, &code);
+    napi_set_named_property(env, err, "status", code);
+    napi_throw(env, err);
+    return nullptr;
+}
+
+bool get_named(napi_env env, napi_value obj, const char *name, napi_value *out)
+{
+    return napi_get_named_property(env, obj, name, out) == napi_ok;
+}
+
+double get_double(napi_env env, napi_value obj, const char *name)
+{
+    napi_value v;
+    double d = 0;
+    if (get_named(env, obj, name, &v)) napi_get_value_double(env, v, &d);
+    return d;
+}
+
+bool get_bool(napi_env env, napi_value obj, const char *name)
+{
+    napi_value v, b;
+    bool r = false;
+    if (get_named(env, obj, name, &v) && napi_coerce_to_bool(env, v, &b) == napi_ok) napi_get_value_bool(env, b, &r);
+    return r;
+}
+
+struct Job {
+    sp_context *ctx = nullptr;
+    sp_request req{};
+    std::vector<double> window;
+    std::vector<uint8_t> lut;
+    const uint8_t *bytes = nullptr;
+    size_t nbytes = 0;
+    int32_t width = 0;
+    // outputs (malloc'd, handed to JS as external ArrayBuffers)
+    uint8_t *rgba = nullptr, *gmin = nullptr, *gmax = nullptr, *gamp = nullptr;
+    std::vector<uint64_t> c_hist, cb_hist;
+    double minmax[2] = {0.0, -200.0};
+    int status = SP_OK;
+    std::string error;
+    // async plumbing
+    napi_async_work work = nullptr;
+    napi_ref cb_ref = nullptr, buf_ref = nullptr;
+};
+
+void free_cb(napi_env, void *data, void *) { free(data); }
+
+bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
+{
+    void *p = nullptr;
+    if (napi_get_value_external(env, handle, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, nullptr, "context handle expected");
+        return false;
+    }
+    j->ctx = (sp_context *)p;
+    napi_value v;
+    int32_t i32 = 0;
+    get_named(env, req, "format", &v); napi_get_value_int32(env, v, &i32); j->req.format = i32;
+    get_named(env, req, "n", &v); napi_get_value_int32(env, v, &i32); j->req.n = i32;
+    get_named(env, req, "width", &v); napi_get_value_int32(env, v, &i32); j->width = i32;
+    j->req.channel_mode = get_bool(env, req, "channelMode");
+    j->req.waterfall = get_bool(env, req, "waterfall");
+    j->req.block_norm = get_double(env, req, "block_norm");
+    j->req.gain = get_double(env, req, "gain");
+    j->req.range = get_double(env, req, "range");
+
+    void *data = nullptr;
+    size_t len = 0;
+    get_named(env, req, "buffer", &v);
+    if (napi_get_arraybuffer_info(env, v, &data, &len) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "buffer must be an ArrayBuffer");
+        return false;
+    }
+    j->bytes = (const uint8_t *)data;
+    j->nbytes = len;
+
+    napi_typedarray_type tt;
+    napi_value ab;
+    size_t off = 0;
+    get_named(env, req, "windowc", &v);
+    if (napi_get_typedarray_info(env, v, &tt, &len, &data, &ab, &off) != napi_ok || tt != napi_float64_array) {
+        napi_throw_type_error(env, nullptr, "windowc must be a Float64Array");
+        return false;
+    }
+    j->window.assign((const double *)data, (const double *)data + len);
+    get_named(env, req, "lut", &v);
+    if (napi_get_typedarray_info(env, v, &tt, &len, &data, &ab, &off) != napi_ok || (tt != napi_uint8_array && tt != napi_uint8_clamped_array)) {
+        napi_throw_type_error(env, nullptr, "lut must be a Uint8Array");
+        return false;
+    }
+    j->lut.assign((const uint8_t *)data, (const uint8_t *)data + len);
+    j->req.lut_len = (int32_t)(len / 3);
+    if ((size_t)j->req.n != j->window.size() && j->req.n > 0 && j->window.size() < (size_t)j->req.n) {
+        napi_throw_range_error(env, nullptr, "windowc is shorter than n");
+        return false;
+    }
+    j->req.windowc = j->window.data();
+    j->req.lut_rgb = j->lut.data();
+    return true;
+}
+
+void run_job(Job *j)
+{
+    const size_t W = j->width > 0 ? (size_t)j->width : 0, n = j->req.n > 0 ? (size_t)j->req.n : 0;
+    j->rgba = (uint8_t *)calloc(4 * W * n + 1, 1);
+    j->gmin = (uint8_t *)calloc(W + 1, 1);
+    j->gmax = (uint8_t *)calloc(W + 1, 1);
+    j->gamp = (uint8_t *)calloc(W + 1, 1);
+    j->c_hist.assign(j->req.lut_len > 0 ? (size_t)j->req.lut_len : 0, 0);
+    j->cb_hist.assign(SP_CB_HIST_SIZE, 0);
+    if (!j->rgba || !j->gmin || !j->gmax || !j->gamp) {
+        j->status = SP_ERR_NOMEM;
+        j->error = "out of host memory";
+        return;
+    }
+    sp_reply r{};
+    r.rgba = j->rgba; r.gauge_mins = j->gmin; r.gauge_maxs = j->gmax; r.gauge_amps = j->gamp;
+    r.c_hist = j->c_hist.data(); r.cb_hist = j->cb_hist.data(); r.dbfs_minmax = j->minmax;
+    j->status = sp_render(j->ctx, &j->req, j->bytes, j->nbytes, j->width, &r);
+    if (j->status != SP_OK) j->error = sp_last_error(j->ctx);
+}
+
+napi_value make_reply(napi_env env, Job *j)
+{
+    const size_t W = j->width > 0 ? (size_t)j->width : 0, n = (size_t)j->req.n;
+    napi_value out, v;
+    NAPI_OK(env, napi_create_object(env, &out));
+    auto put_ab = [&](const char *name, uint8_t *&p, size_t len) {
+        napi_value ab;
+        if (napi_create_external_arraybuffer(env, p, len, free_cb, nullptr, &ab) == napi_ok) {
+            p = nullptr;   // owned by the ArrayBuffer now
+            napi_set_named_property(env, out, name, ab);
+        }
+    };
+    put_ab("rgba", j->rgba, 4 * W * n);
+    put_ab("gauge_mins", j->gmin, W);
+    put_ab("gauge_maxs", j->gmax, W);
+    put_ab("gauge_amps", j->gamp, W);
+    auto put_hist = [&](const char *name, const std::vector<uint64_t> &h) {
+        napi_value ab, ta;
+        void *data;
+        if (napi_create_arraybuffer(env, h.size() * 8, &data, &ab) != napi_ok) return;
+        for (size_t i = 0; i < h.size(); i++) ((double *)data)[i] = (double)h[i];
+        napi_create_typedarray(env, napi_float64_array, h.size(), ab, 0, &ta);
+        napi_set_named_property(env, out, name, ta);
+    };
+    put_hist("c_hist", j->c_hist);
+    put_hist("cB_hist", j->cb_hist);
+    napi_create_double(env, j->minmax[0], &v); napi_set_named_property(env, out, "dBfs_min", v);
+    napi_create_double(env, j->minmax[1], &v); napi_set_named_property(env, out, "dBfs_max", v);
+    return out;
+}
+
+void free_job(napi_env env, Job *j)
+{
+    free(j->rgba); free(j->gmin); free(j->gmax); free(j->gamp);
+    if (j->cb_ref) napi_delete_reference(env, j->cb_ref);
+    if (j->buf_ref) napi_delete_reference(env, j->buf_ref);
+    if (j->work) napi_delete_async_work(env, j->work);
+    delete j;
+}
+
+napi_value make_error(napi_env env, Job *j)
+{
+    napi_value err, text, code;
+    const std::string m = j->error.empty() ? sp_status_string(j->status) : j->error;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &text);
+    napi_create_error(env, nullptr, text, &err);
+    napi_create_int32(env, j->status, &code);
+    napi_set_named_property(env, err, "status", code);
+    return err;
+}
+
+napi_value RenderSync(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Job *j = new Job;
+    if (!parse_request(env, argv[0], argv[1], j)) { free_job(env, j); return nullptr; }
+    run_job(j);
+    napi_value out = nullptr;
+    if (j->status != SP_OK) napi_throw(env, make_error(env, j));
+    else out = make_reply(env, j);
+    free_job(env, j);
+    return out;
+}
+
+void exec_cb(napi_env, void *data) { run_job((Job *)data); }
+
+void done_cb(napi_env env, napi_status, void *data)
+{
+    Job *j = (Job *)data;
+    napi_value cb, global, argv[2];
+    napi_get_reference_value(env, j->cb_ref, &cb);
+    napi_get_global(env, &global);
+    if (j->status != SP_OK) {
+        argv[0] = make_error(env, j);
+        napi_get_undefined(env, &argv[1]);
+    } else {
+        napi_get_null(env, &argv[0]);
+        argv[1] = make_reply(env, j);
+    }
+    napi_value ignored;
+    napi_call_function(env, global, cb, 2, argv, &ignored);
+    free_job(env, j);
+}
+
+napi_value Render(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Job *j = new Job;
+    if (!parse_request(env, argv[0], argv[1], j)) { free_job(env, j); return nullptr; }
+    napi_value buf, name;
+    napi_get_named_property(env, argv[1], "buffer", &buf);
+    napi_create_reference(env, buf, 1, &j->buf_ref);     // keep the input alive while the worker thread reads it
+    napi_create_reference(env, argv[2], 1, &j->cb_ref);
+    napi_create_string_utf8(env, "spectroplot_hip.render", NAPI_AUTO_LENGTH, &name);
+    NAPI_OK(env, napi_create_async_work(env, nullptr, name, exec_cb, done_cb, j, &j->work));
+    NAPI_OK(env, napi_queue_async_work(env, j->work));
+    return nullptr;
+}
+
+napi_value DeviceCount(napi_env env, napi_callback_info)
+{
+    int32_t c = 0;
+    sp_device_count(&c);
+    napi_value v;
+    napi_create_int32(env, c, &v);
+    return v;
+}
+
+napi_value ParseFormat(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1], s;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    NAPI_OK(env, napi_coerce_to_string(env, argv[0], &s));
+    char buf[64];
+    size_t len = 0;
+    napi_get_value_string_utf8(env, s, buf, sizeof buf, &len);
+    int32_t id = 0, sw = 0;
+    sp_format_parse(buf, &id, &sw);
+    napi_value out, v;
+    napi_create_object(env, &out);
+    napi_create_int32(env, id, &v); napi_set_named_property(env, out, "id", v);
+    napi_create_int32(env, sw, &v); napi_set_named_property(env, out, "sampleWidth", v);
+    napi_create_int32(env, sp_format_element_size(id), &v); napi_set_named_property(env, out, "elementSize", v);
+    return out;
+}
+
+napi_value Window(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    char name[64];
+    size_t len = 0;
+    int32_t n = 0;
+    napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len);
+    napi_get_value_int32(env, argv[1], &n);
+    if (n < 1) return throw_status(env, SP_ERR_INVALID_ARG, "n must be positive");
+    napi_value ab, ta, out, w;
+    void *data;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)n * 8, &data, &ab));
+    double weight = 0;
+    const int rc = sp_window(name, n, (double *)data, &weight);
+    if (rc) return throw_status(env, rc, "unknown window name");
+    napi_create_typedarray(env, napi_float64_array, (size_t)n, ab, 0, &ta);
+    napi_create_object(env, &out);
+    napi_set_named_property(env, out, "window", ta);
+    napi_create_double(env, weight, &w);
+    napi_set_named_property(env, out, "weight", w);
+    return out;
+}
+
+napi_value SliceBounds(napi_env env, napi_callback_info info)
+{
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    double nbytes = 0;
+    int32_t sw = 0, index = 0, count = 0;
+    napi_get_value_double(env, argv[0], &nbytes);
+    napi_get_value_int32(env, argv[1], &sw);
+    napi_get_value_int32(env, argv[2], &index);
+    napi_get_value_int32(env, argv[3], &count);
+    size_t b = 0, e = 0;
+    const int rc = sp_slice_bounds((size_t)nbytes, sw, index, count, &b, &e);
+    if (rc) return throw_status(env, rc, nullptr);
+    napi_value out, v;
+    napi_create_array_with_length(env, 2, &out);
+    napi_create_double(env, (double)b, &v); napi_set_element(env, out, 0, v);
+    napi_create_double(env, (double)e, &v); napi_set_element(env, out, 1, v);
+    return out;
+}
+
+void ctx_finalize(napi_env, void *data, void *) { sp_context_destroy((sp_context *)data); }
+
+napi_value CreateContext(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t dev = 0;
+    if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
+    sp_context *ctx = nullptr;
+    const int rc = sp_context_create(dev, &ctx);
+    if (rc) return throw_status(env, rc, rc == SP_ERR_NO_DEVICE ? "no HIP device: spectroplot-hip has no CPU fallback" : nullptr);
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, ctx, ctx_finalize, nullptr, &ext));
+    return ext;
+}
+
+napi_value Init(napi_env env, napi_value exports)
+{
+    const napi_property_descriptor props[] = {
+        {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"parseFormat", nullptr, ParseFormat, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"window", nullptr, Window, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"sliceBounds", nullptr, SliceBounds, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"createContext", nullptr, CreateContext, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"renderSync", nullptr, RenderSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+    napi_value v;
+    napi_create_int32(env, sp_version(), &v);
+    napi_set_named_property(env, exports, "version", v);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

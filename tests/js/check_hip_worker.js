@@ -1,0 +1,81 @@
+'use strict'
+/**
+ * GPU: every golden vector of the real reference worker through the Worker-shaped HipWorker (postMessage -> onmessage),
+ * plus the contract details of the drop-in seam: probe messages ignored, one reply per request in FIFO order,
+ * error events where the reference would throw, slice + merge over a worker pool.
+ */
+const assert = require('assert')
+const G = require('./golden_util.js')
+const O = require('../../oracle/js/worker_oracle.js')   // only for makeWindow (taper values are inputs of the message)
+const { HipWorker, renderSliced } = require('../../spectroplot-js_amd/js')
+
+function ask(worker, message) {
+    return new Promise((resolve, reject) => {
+        worker.onmessage = (e) => resolve(e.data)
+        worker.onerror = (e) => reject(e)
+        worker.postMessage(message, [message.buffer])
+    })
+}
+
+async function main() {
+    const worker = new HipWorker()
+    let failures = []
+    let checked = 0
+    for (const c of G.spec.worker_cases) {
+        const e = G.expected.find(x => x.name === c.name)
+        const pow2 = (c.n & (c.n - 1)) === 0
+        const { window: windowc, weight } = pow2 ? O.makeWindow(c.window, c.n) : { window: new Array(c.n).fill(1), weight: c.n }
+        const cmap = G.getCmap(c)
+        const message = { block_norm: 1.0 / weight, gain: c.gain, range: c.range, cmap, n: c.n, windowc, width: c.width, offset: c.offset || 0,
+            buffer: G.makeInput(c), format: c.format, channelMode: !!c.channelMode, waterfall: !!c.waterfall }
+        if (e.throws) {
+            let err = null
+            try { await ask(worker, message) } catch (ev) { err = ev }
+            if (!err) failures.push(`${c.name}: expected an error event`)
+            else if (/power of 2/.test(e.throws) && err.status !== -2) failures.push(`${c.name}: status ${err.status}`)
+            else if (/multiple/.test(e.throws) && err.status !== -3) failures.push(`${c.name}: status ${err.status}`)
+        } else if (e.reply) {
+            const r = await ask(worker, message)
+            const bad = G.compareReply(r, e.reply)
+            if (bad.length) failures.push(`${c.name}: ${bad.join(',')}`)
+        } else {
+            const pool = Array.from({ length: Math.min(c.slices, 3) }, () => new HipWorker())
+            const m = await renderSliced({ buffer: message.buffer, format: c.format, n: c.n, width: c.width, workers: c.slices,
+                window: { window: windowc, weight }, cmap: G.getCmap(c, false), gain: c.gain, range: c.range,
+                channelMode: !!c.channelMode, waterfall: !!c.waterfall }, pool)
+            if (!c.force_ends) throw new Error('slice cases force the LUT ends')
+            m.replies.forEach((r, i) => { const bad = G.compareReply(r, e.slices[i]); if (bad.length) failures.push(`${c.name}[${i}]: ${bad.join(',')}`) })
+            if (G.sha256(m.data) !== e.merged.rgba_sha256) failures.push(`${c.name}: merged rgba`)
+            if (JSON.stringify(m.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: merged c_hist`)
+            if (!G.sameF64(m.dBfs_min, e.merged.dBfs_min) || !G.sameF64(m.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: merged range`)
+            pool.forEach(w => w.terminate())
+        }
+        checked++
+    }
+
+    // the transferable probe (lib/spectroplot.js:118-119) and other buffer-less messages produce no reply
+    let got = 0
+    worker.onmessage = () => { got++ }
+    worker.postMessage({ transferable: new ArrayBuffer(1) })
+    worker.postMessage(null)
+    worker.postMessage({})
+    // FIFO: replies come back in request order even when the requests differ in cost
+    const order = []
+    const c1 = G.spec.worker_cases.find(x => x.name === 'cfg2_scaled'), c2 = G.spec.worker_cases.find(x => x.name === 'tiny_keep')
+    const mk = (c, tag) => {
+        const { window: windowc, weight } = O.makeWindow(c.window, c.n)
+        return { block_norm: 1.0 / weight, gain: c.gain, range: c.range, cmap: G.getCmap(c), n: c.n, windowc, width: c.width, offset: tag,
+            buffer: G.makeInput(c), format: c.format, channelMode: false, waterfall: false }
+    }
+    await new Promise((resolve) => {
+        worker.onmessage = (e) => { order.push(e.data.offset); if (order.length === 4) resolve() }
+        worker.postMessage(mk(c1, 1)); worker.postMessage(mk(c2, 2)); worker.postMessage(mk(c1, 3)); worker.postMessage(mk(c2, 4))
+    })
+    assert.deepStrictEqual(order, [1, 2, 3, 4])
+    assert.strictEqual(got, 0)
+
+    if (failures.length) { console.error(failures.slice(0, 30).join('\n')); console.error(`${failures.length} failures`); process.exit(1) }
+    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s)`)
+}
+
+main().catch(e => { console.error(e); process.exit(1) })

@@ -1,0 +1,30 @@
+"""The Node.js host layer: N-API addon + HipWorker (the object handed to the reference through `workerOrUrl`)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from __graft_entry__ import ROOT, build
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+ADDON = os.path.join(ROOT, "spectroplot-js_amd", "lib", "spectroplot_hip.node")
+
+
+def _node(script, timeout=600):
+    if not os.path.exists(ADDON):
+        build()
+    return subprocess.run(["node", os.path.join(ROOT, "tests", "js", script)], capture_output=True, text=True, timeout=timeout)
+
+
+def test_addon_loads_and_host_helpers_match_reference_kats():
+    out = _node("check_addon_cpu.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "addon cpu checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_hip_worker_reproduces_golden_vectors():
+    out = _node("check_hip_worker.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bit-for-bit" in out.stdout
