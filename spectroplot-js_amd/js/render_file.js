@@ -31,17 +31,22 @@ function renderSliced(o, pool) {
     const merged = new Uint8ClampedArray(4 * width * n)
     const c_hist = new Array(cmap.length).fill(0), cB_hist = new Array(1000).fill(0)
     let dBfs_min = 0.0, dBfs_max = -200.0
+    // one FIFO of resolvers per worker, like the reference's renderCallbacks (lib/spectroplot.js:89-98, :111-115)
+    const pending = pool.map(() => [])
+    const saved = pool.map(wk => [wk.onmessage, wk.onerror])
+    pool.forEach((wk, k) => {
+        wk.onmessage = (e) => { const p = pending[k].shift(); if (p) p.resolve(e.data) }
+        wk.onerror = (e) => { const p = pending[k].shift(); if (p) p.reject(e.error || new Error(e.message)) }
+    })
     const jobs = []
     for (let i = 0; i < workers; i++) {
         const [b0, b1] = a.sliceBounds(o.buffer.byteLength, fmt.sampleWidth, i, workers)
         const message = { block_norm, gain, range, cmap, n, windowc: w.window, width: sliceWidth, offset: i * sliceWidth,
             buffer: o.buffer.slice(b0, b1), format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+        const k = i % pool.length
         jobs.push(new Promise((resolve, reject) => {
-            const wk = pool[i % pool.length]
-            const prevM = wk.onmessage, prevE = wk.onerror
-            wk.onmessage = (e) => { wk.onmessage = prevM; wk.onerror = prevE; resolve(e.data) }
-            wk.onerror = (e) => { wk.onmessage = prevM; wk.onerror = prevE; reject(e.error || new Error(e.message)) }
-            wk.postMessage(message, [message.buffer])
+            pending[k].push({ resolve, reject })
+            pool[k].postMessage(message, [message.buffer])
         }))
     }
     return Promise.all(jobs).then(replies => {
@@ -57,6 +62,7 @@ function renderSliced(o, pool) {
                 merged.set(img, 4 * n * (width - sliceWidth - r.offset))
             }
         }
+        pool.forEach((wk, k) => { wk.onmessage = saved[k][0]; wk.onerror = saved[k][1] })
         if (own) pool.forEach(wk => wk.terminate())
         return { data: merged, width: o.waterfall ? n : width, height: o.waterfall ? width : n, c_hist, cB_hist, dBfs_min, dBfs_max,
             sliceWidth, replies }
