@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two gloo ranks play two reference workers.  The per-rank renderer is injected — here the C oracle,
+because no GPU exists in this container (the product's own renderer is HipWorker.render) — so what is tested is the
+slicing, the collectives and the strip placement, against the reference's merged vectors for 2 workers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from __graft_entry__ import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, case_names, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import goldenlib
+    from __graft_entry__ import load_package
+    from oracle import pyoracle
+    pkg = load_package()
+    from spectroplot_js_amd import sharding
+    g = goldenlib.Golden()
+
+    def oracle_worker(m):   # stands in for HipWorker.render on a GPU-less box (tests may use the oracle)
+        lut = np.asarray(m["cmap"], dtype=np.uint8)
+        r = pyoracle.render(m["format"], m["buffer"], m["n"], m["windowc"], m["block_norm"], m["gain"], m["range"], lut, m["width"],
+                            m["channelMode"], m["waterfall"])
+        return {"cB_hist": r["cB_hist"], "c_hist": r["c_hist"], "dBfs_min": r["dBfs_min"], "dBfs_max": r["dBfs_max"],
+                "offset": m["offset"], "imageData": {"data": r["rgba"]}}
+
+    ok = True
+    for name in case_names:
+        c, e = g.cases[name], g.expected[name]
+        data = g.input(c)
+        win, weight = pyoracle.window(c["window"], c["n"])
+        cmap = g.lut(c, force_ends=False).tolist()
+        m = sharding.render_sharded(oracle_worker, data, c["format"], c["n"], c["width"], win, weight, cmap, c["gain"], c["range"],
+                                    c["channelMode"], c["waterfall"], force_ends=c["force_ends"])
+        ok &= [int(v) for v in m["c_hist"]] == e["merged"]["c_hist"]
+        ok &= goldenlib.same_f64(m["dBfs_min"], e["merged"]["dBfs_min"]) and goldenlib.same_f64(m["dBfs_max"], e["merged"]["dBfs_max"])
+        ok &= m["slice_width"] == e["merged"]["slice_width"]
+        ok &= not goldenlib.check_reply({"rgba": m["reply"]["imageData"]["data"], "gauge_mins": b"", "gauge_maxs": b"", "gauge_amps": b"",
+                                         "c_hist": m["reply"]["c_hist"], "cB_hist": m["reply"]["cB_hist"], "dBfs_min": m["reply"]["dBfs_min"],
+                                         "dBfs_max": m["reply"]["dBfs_max"]},
+                                        dict(e["slices"][rank], gauge_mins="", gauge_maxs="", gauge_amps=""))
+        if rank == 0:
+            ok &= goldenlib.sha256(m["data"]) == e["merged"]["rgba_sha256"]
+        else:
+            ok &= m["data"] is None
+    with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+        f.write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_reference_two_worker_merge(tmp_path, golden):
+    names = [n for n, c in golden.cases.items() if c.get("slices") == 2]
+    assert len(names) >= 3
+    mp.spawn(_rank_main, args=(2, _free_port(), names, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "rank0").read() == "ok"
+    assert open(tmp_path / "rank1").read() == "ok"
