@@ -520,8 +520,10 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     int rc = ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
     const int finish_blocks = (width + spk::kFinishThreads - 1) / spk::kFinishThreads;
-    rc = ctx->partial.reserve(2 * (size_t)finish_blocks * sizeof(double));
+    const bool fresh_partial = ctx->partial.cap < 2 * (size_t)finish_blocks * sizeof(double) + 64;
+    rc = ctx->partial.reserve(2 * (size_t)finish_blocks * sizeof(double) + 64);   // + the arrival ticket
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
+    if (fresh_partial) SP_HIP(ctx, hipMemsetAsync(ctx->partial.p, 0, ctx->partial.cap, s));
 
     spk::FrameArgs a{};
     a.bytes = (const uint8_t *)d_bytes;
@@ -622,10 +624,10 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     fa.gauge_mins = out->gauge_mins;
     fa.gauge_maxs = out->gauge_maxs;
     fa.gauge_amps = out->gauge_amps;
-    fa.partial = (double *)ctx->partial.p;
+    fa.partial = (double *)ctx->partial.p + 8;
+    fa.ticket = (unsigned int *)ctx->partial.p;
+    fa.out_minmax = out->dbfs_minmax;
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);
-    if (out->dbfs_minmax)
-        hipLaunchKernelGGL(spk::k_finish_reduce, dim3(1), dim3(256), 0, s, (const double *)ctx->partial.p, finish_blocks, out->dbfs_minmax);
     SP_HIP(ctx, hipGetLastError());
     return SP_OK;
 }

@@ -54,7 +54,7 @@ __host__ __device__ inline int lds_group_frames(int n, int want)
 // Stages 5..kLdsTwMaxStage keep their twiddle tables in LDS (table of stage s = entries [2^(s-1), 2^s) of stage_tw);
 // stages 1-4 have lane-uniform twiddles (scalar loads) and stages above kLdsTwMaxStage read HBM/L2.
 constexpr int kLdsTwMaxStage = 10;
-__host__ __device__ inline int lds_tw_entries(int n)
+__host__ __device__ inline constexpr int lds_tw_entries(int n)
 {
     const int top = n < (1 << kLdsTwMaxStage) ? n : (1 << kLdsTwMaxStage);
     return top > 16 ? top - 16 : 0;
@@ -224,14 +224,42 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     const int tile_pitch = N + kTilePad;
     const int cmax = a.lut_len - 1;
 
-    for (int i = tid; i < a.lut_len; i += kLdsThreads) {
-        s_gedge[i] = a.gray_edge[i];
-        s_lut[i] = a.lut_rgba[i];
-        s_chist[i] = 0;
+    {
+        // request tables -> LDS: every global load is issued before the first LDS store, so the prologue costs one memory
+        // latency instead of one per table (it is a visible share of a launch at the 16 k-frame size of config 2)
+        constexpr int NTW = lds_tw_entries(N);
+        constexpr int TWK = (NTW + kLdsThreads - 1) / kLdsThreads;
+        double2 tw_r[TWK > 0 ? TWK : 1];
+#pragma unroll
+        for (int k = 0; k < TWK; k++) {
+            const int i = tid + k * kLdsThreads;
+            tw_r[k] = i < NTW ? stage_tw[16 + i] : make_double2(0.0, 0.0);
+        }
+        const double ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;            // lut_len <= 256 < kLdsThreads
+        const unsigned int lut_r = tid < a.lut_len ? a.lut_rgba[tid] : 0u;
+        double cb_r[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * kLdsThreads;
+            cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < TWK; k++) {
+            const int i = tid + k * kLdsThreads;
+            if (i < NTW) s_tw[i] = tw_r[k];
+        }
+        if (tid < a.lut_len) {
+            s_gedge[tid] = ge_r;
+            s_lut[tid] = lut_r;
+            s_chist[tid] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * kLdsThreads;
+            if (i <= SP_CB_HIST_SIZE) s_cbedge[i] = cb_r[k];
+            if (i < SP_CB_HIST_SIZE) s_cbhist[i] = 0;
+        }
     }
-    for (int i = tid; i <= SP_CB_HIST_SIZE; i += kLdsThreads) s_cbedge[i] = a.cb_edge[i];
-    for (int i = tid; i < lds_tw_entries(N); i += kLdsThreads) s_tw[i] = stage_tw[16 + i];
-    for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads) s_cbhist[i] = 0;
 
     // taper coefficients of this thread's 16 samples stay in registers for the whole launch
     double win[16];

@@ -134,7 +134,9 @@ struct FinishArgs {
     double block_norm_db, gain, range;
     const double *frame_min, *frame_max;
     uint8_t *gauge_mins, *gauge_maxs, *gauge_amps;
-    double *partial;   // [gridDim.x * 2]
+    double *partial;          // [gridDim.x * 2]
+    unsigned int *ticket;     // arrival counter, zero before and after every launch
+    double *out_minmax;       // [2] or nullptr
 };
 
 // store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
@@ -193,40 +195,50 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
         s_red[2 * (threadIdx.x >> 6) + 1] = dmax;
     }
     __syncthreads();
+    __shared__ bool s_last;
     if (threadIdx.x == 0) {
         for (int w = 1; w < kFinishThreads / 64; w++) {
             dmin = fmin(dmin, s_red[2 * w]);
             dmax = fmax(dmax, s_red[2 * w + 1]);
         }
-        a.partial[2 * blockIdx.x] = dmin;
-        a.partial[2 * blockIdx.x + 1] = dmax;
+        // publish this block's partial, then take a ticket: the block that arrives last reduces all partials
+        // (agent-scope release on the producers, acquire on the consumer; write-through stores so no L2 line stays dirty)
+        __hip_atomic_store(&a.partial[2 * blockIdx.x], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partial[2 * blockIdx.x + 1], dmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
     }
-}
-
-__global__ __launch_bounds__(256) void k_finish_reduce(const double *partial, int count, double *out_minmax)
-{
-    __shared__ double s_red[8];
-    double dmin = 0.0, dmax = -200.0;
-    for (int i = threadIdx.x; i < count; i += 256) {
-        dmin = fmin(dmin, partial[2 * i]);
-        dmax = fmax(dmax, partial[2 * i + 1]);
+    __syncthreads();
+    if (!s_last || !a.out_minmax) {
+        if (s_last && threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double rmin = 0.0, rmax = -200.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kFinishThreads) {
+        rmin = fmin(rmin, __hip_atomic_load(&a.partial[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        rmax = fmax(rmax, __hip_atomic_load(&a.partial[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     for (int off = 32; off > 0; off >>= 1) {
-        dmin = fmin(dmin, __shfl_xor(dmin, off));
-        dmax = fmax(dmax, __shfl_xor(dmax, off));
+        rmin = fmin(rmin, __shfl_xor(rmin, off));
+        rmax = fmax(rmax, __shfl_xor(rmax, off));
     }
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        s_red[2 * (threadIdx.x >> 6)] = dmin;
-        s_red[2 * (threadIdx.x >> 6) + 1] = dmax;
+        s_red[2 * (threadIdx.x >> 6)] = rmin;
+        s_red[2 * (threadIdx.x >> 6) + 1] = rmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
-            dmin = fmin(dmin, s_red[2 * w]);
-            dmax = fmax(dmax, s_red[2 * w + 1]);
+        for (int w = 1; w < kFinishThreads / 64; w++) {
+            rmin = fmin(rmin, s_red[2 * w]);
+            rmax = fmax(rmax, s_red[2 * w + 1]);
         }
-        out_minmax[0] = dmin;
-        out_minmax[1] = dmax;
+        a.out_minmax[0] = rmin;
+        a.out_minmax[1] = rmax;
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
