@@ -160,6 +160,50 @@ __device__ inline void exchange(double (&v)[16], double *from, const double *to)
     for (int e = 0; e < 16; e++) v[e] = to[win_off(e, WS_TO)];
 }
 
+// ---- second re-distribution without LDS (n = 512, 1024; one frame per wave or half-wave) ----------------------------
+// After the pass over window [4,8) the stage bits of the last pass sit in the lane index (p8, p9 = lane bits 4, 5) and
+// two of the register-index bits (p4, p5) must become lane bits.  That is a transpose between register pairs and the
+// 16-lane rows / 32-lane halves of the wavefront, which gfx950 does in the VALU: v_permlane16_swap exchanges the odd rows
+// of one register with the even rows of another, v_permlane32_swap the upper half of one with the lower half of another.
+__device__ inline void swap_rows16(double &a, double &b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ inline void swap_halves32(double &a, double &b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// window [4,8) -> window [LOG2N-4, LOG2N) for LOG2N = 9, 10, in registers
+template <int LOG2N>
+__device__ inline void exchange_permlane(double (&v)[16])
+{
+    static_assert(LOG2N == 9 || LOG2N == 10, "only the 512- and 1024-point layouts put the stage bits in lane bits 4/5");
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) swap_rows16(v[e], v[e + 1]);              // register bit 0 (p4) <-> lane bit 4 (p8)
+    if constexpr (LOG2N == 10) {
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if (!(e & 2)) swap_halves32(v[e], v[e | 2]);                       // register bit 1 (p5) <-> lane bit 5 (p9)
+    }
+    // rename registers to the standard order of the new window: index bits (p[L-4] .. p[L-1])
+    double t[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int std_idx = LOG2N == 10 ? (((e >> 2) & 3) | ((e & 3) << 2))    // ours (p8,p9,p6,p7) -> (p6,p7,p8,p9)
+                                        : ((e >> 1) | ((e & 1) << 3));          // ours (p8,p5,p6,p7) -> (p5,p6,p7,p8)
+        t[std_idx] = v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = t[e];
+}
+
 template <int FMT>
 __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, int64_t start, int tl, int T, int levels,
                                   const double (&win)[16], double (&re)[16], double (&im)[16])
@@ -192,6 +236,20 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
         }
     }
 }
+
+// Diagnostic build only (make STAMPS=1): per-phase s_memtime totals of wave 0 of every workgroup go to a.stamps.  The stamp's
+// own s_waitcnt drains outstanding LDS/SMEM operations, so such a build shows SHARES of a frame, never a valid run time.
+#ifdef SP_STAMPS
+#define SP_STAMP(k)                                                                             \
+    do {                                                                                        \
+        unsigned long long t_;                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+        stamp_acc[k] += t_ - stamp_prev;                                                        \
+        stamp_prev = t_;                                                                        \
+    } while (0)
+#else
+#define SP_STAMP(k) do { } while (0)
+#endif
 
 template <int LOG2N, bool CH>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
@@ -272,6 +330,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
+#ifdef SP_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     // clipped colour indices and the end bins of the centi-bel histogram are counted in per-lane registers
     // (they dominate typical images and would serialise as same-address LDS atomics)
     unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
@@ -291,6 +353,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             const bool live = xr < a.width;
             const int x = live ? xr : a.width - 1;  // surplus slots recompute the last frame and discard it
             const int64_t start = frame_start(a.stride, x);
+            SP_STAMP(0);   // loop control
 
             // Touch the cache lines of the frame this slot processes next, so that its loads hit L2 instead of HBM.
             asm volatile("" ::"v"(pf_word));   // the previous touch has long landed; this only keeps the load alive
@@ -319,21 +382,32 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
+            SP_STAMP(1);   // touch + input loads + decode + taper
             fft_pass<0, 1, 4>(re, im, tl, s_tw, stage_tw);
+            SP_STAMP(2);   // pass 0
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                SP_STAMP(3);   // exchange 1 (LDS)
                 fft_pass<WS1, 5, E1>(re, im, tl, s_tw, tw);
+                SP_STAMP(4);   // pass 1
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
-                    exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
-                    exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                    if constexpr (LOG2N == 9 || LOG2N == 10) {
+                        exchange_permlane<LOG2N>(re);      // no LDS: v_permlane16_swap / v_permlane32_swap
+                        exchange_permlane<LOG2N>(im);
+                    } else {
+                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
+                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                    }
+                    SP_STAMP(5);   // exchange 2 (permlane or LDS)
                     fft_pass<WS2, 9, E2>(re, im, tl, s_tw, tw);
+                    SP_STAMP(6);   // pass 2
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
@@ -397,6 +471,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 gc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
                 lc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
             }
+            SP_STAMP(7);   // abs2 + first guesses
             double ge[16], ce[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -422,6 +497,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 cnt_cb_last += (live && !special && l0) ? 1u : 0u;
                 atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
             }
+            SP_STAMP(8);   // edge reads, compares, tile bytes, histogram atomics
             // frame min / max over its T threads
 #pragma unroll
             for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) {
@@ -440,7 +516,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 }
             }
         }
+        SP_STAMP(9);   // frame min/max reduction + stores
         __syncthreads();   // tile complete
+        SP_STAMP(10);  // waiting for the other waves of the group
 
         if constexpr (WPF > 1) {
             if (tid < group_frames && x0 + tid < a.width) {
@@ -503,8 +581,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
         }
         __syncthreads();   // tile and s_mm are reused by the next group
+        SP_STAMP(11);  // tile -> RGBA write-out + barrier
     }
 
+#ifdef SP_STAMPS
+    if (a.stamps && (tid & 63) == 0) {
+        for (int k = 0; k < 12; k++) atomicAdd(&a.stamps[k], stamp_acc[k]);
+        atomicAdd(&a.stamps[12], 1ull);
+    }
+#endif
     // ---- flush histograms ----------------------------------------------------------------------------------------
     if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);          // per-lane counters of the clipped / end bins
     if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);

@@ -32,6 +32,7 @@ struct FrameArgs {
     double *frame_min;           // [width] min over the frame of abs2 (NaN ignored), +inf if none
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
+    unsigned long long *stamps;  // diagnostic builds (SP_STAMPS): 13 counters, else nullptr
 };
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
