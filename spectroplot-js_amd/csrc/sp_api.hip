@@ -59,7 +59,6 @@ struct sp_context {
     DeviceBuffer frame_minmax;   // 2 * width doubles
     DeviceBuffer partial;        // finish-kernel partials
     DeviceBuffer scratch;        // scratch kernel slabs
-    DeviceBuffer gray;           // colour-index plane between k_wave_r16 and k_colorize (one cache-resident chunk)
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small, hist_dummy;
     sp_plan *cached_plan = nullptr;
@@ -236,7 +235,6 @@ extern "C" void sp_context_destroy(sp_context *ctx)
     ctx->frame_minmax.release();
     ctx->partial.release();
     ctx->scratch.release();
-    ctx->gray.release();
     ctx->in_bytes.release();
     ctx->out_rgba.release();
     ctx->render_small.release();
@@ -453,6 +451,10 @@ static bool plan_wave_capable(const sp_plan *plan) { return plan_lds_capable(pla
 static int plan_kernel(const sp_plan *plan)
 {
     if (plan->force_kernel) return plan->force_kernel;
+    static const int env_kernel = getenv("SP_FORCE_KERNEL") ? atoi(getenv("SP_FORCE_KERNEL")) : 0;   // experiments only
+    if (env_kernel == 3 && plan_wave_capable(plan)) return 3;
+    if (env_kernel == 2 && plan_lds_capable(plan)) return 2;
+    if (env_kernel == 1) return 1;
     // The fused LDS kernel is the default.  The two-kernel variant (3) measured no faster on MI355X (its extra waves
     // are spent on LDS / f64 issue contention, DESIGN.md "What was tried"); it stays selectable for comparison.
     if (plan_lds_capable(plan)) return 2;
@@ -472,7 +474,7 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 {
     if (!plan) return "";
     switch (plan_kernel(plan)) {
-    case 3: return "wave_r16+colorize";
+    case 3: return "wave_r16";
     case 2: return "lds_r16";
     default: return "scratch_radix2";
     }
@@ -590,18 +592,9 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.cb_hist = cb_hist;
 
     const int which = plan_kernel(plan);
-    if (which == 3) {
-        // colour-index plane: one chunk of at most 24 MiB, so that it is still cache resident when k_colorize reads it
-        size_t want = (size_t)width * (size_t)n;
-        const size_t cap = (size_t)24 << 20;
-        if (want > cap) want = cap;
-        want = (want + 64 * (size_t)n - 1) / (64 * (size_t)n) * (64 * (size_t)n);
-        rc = ctx->gray.reserve(want);
-        if (rc) return fail(ctx, rc, "colour-index plane: out of device memory");
-    }
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (which == 3) {
-        rc = spk::launch_wave(a, plan->req.format, plan->d_stage_tw, (uint8_t *)ctx->gray.p, ctx->gray.cap, ctx->cu_count, s);
+        rc = spk::launch_wave(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
         if (rc) return fail(ctx, rc, "wave kernel launch rejected the configuration");
     } else if (which == 2) {
         rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
