@@ -180,4 +180,38 @@ SP_HD inline void sample_fast(const uint8_t *p, int64_t pos, double &vi, double 
     }
 }
 
+// Both components from the raw little-endian words of one sample that is already in registers (2-, 4- and 8-byte samples:
+// lo = the first four bytes, hi = the next four).  Same arithmetic as sample_fast.
+template <int FMT>
+SP_HD inline void decode_raw(uint32_t lo, uint32_t hi, double &vi, double &vq)
+{
+    const Format f = describe(FMT);
+    if constexpr (FMT == SP_FMT_CU8) {
+        vi = ((double)(lo & 0xff) - f.bias) * f.scale;
+        vq = ((double)((lo >> 8) & 0xff) - f.bias) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CS8) {
+        vi = (double)(int8_t)(lo & 0xff) * f.scale;
+        vq = (double)(int8_t)((lo >> 8) & 0xff) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CU16) {
+        vi = ((double)(lo & 0xffff) - f.bias) * f.scale;
+        vq = ((double)(lo >> 16) - f.bias) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CS16) {
+        vi = (double)(int16_t)(lo & 0xffff) * f.scale;
+        vq = (double)(int16_t)(lo >> 16) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CU32) {
+        vi = ((double)lo - f.bias) * f.scale;
+        vq = ((double)hi - f.bias) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CS32) {
+        vi = (double)(int32_t)lo * f.scale;
+        vq = (double)(int32_t)hi * f.scale;
+    } else {
+        static_assert(FMT == SP_FMT_CF32, "decode_raw covers the 2-, 4- and 8-byte sample formats");
+        float a, b;
+        memcpy(&a, &lo, 4);
+        memcpy(&b, &hi, 4);
+        vi = (double)a;
+        vq = (double)b;
+    }
+}
+
 }  // namespace spfmt

@@ -60,10 +60,12 @@ __host__ __device__ inline constexpr int lds_tw_entries(int n)
     return top > 16 ? top - 16 : 0;
 }
 
+__host__ __device__ inline constexpr bool lds_win_in_lds(int n) { return n <= 1024; }
+
 struct LdsLayout {
     int xch_doubles;   // exchange buffer (all frames of a round)
     int tile_bytes;
-    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, off_tw, off_trash, total;
+    int off_tile, off_lut, off_chist, off_cbhist, off_gedge, off_cbedge, off_mm, off_tw, off_trash, off_win, total;
 };
 
 __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_frames)
@@ -82,6 +84,8 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_fr
     l.off_chist = o;  o += lut_len * 4;
     l.off_cbhist = o; o += SP_CB_HIST_SIZE * 4;
     l.off_trash = o;  o += kLdsThreads * 4;
+    o = (o + 7) & ~7;
+    l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;   // taper (n <= 1024: frees 32 VGPRs for the input prefetch)
     l.total = (o + 15) & ~15;
     return l;
 }
@@ -111,6 +115,8 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, cons
 {
 #pragma unroll
     for (int s = S0; s <= S1; s++) {
+        // keep the twiddle reads of a stage from being hoisted above the previous stage: at most 8 (x4 VGPRs) are live
+        if (WS > 0 && s > S0) asm volatile("" ::: "memory");
         const int u = (s - 1) - WS;          // bit of the register index toggled by this stage
         const int half = 1 << (s - 1);
         const int tl_low = tl & ((1 << WS) - 1);
@@ -237,6 +243,43 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
     }
 }
 
+// ---- next-frame input prefetch into registers (2-, 4- and 8-byte samples, frames inside the buffer) --------------------
+// The raw words of the NEXT frame are requested right after the current frame has been decoded and are consumed one frame
+// later, so HBM latency is covered by a whole frame of butterflies; no other vector-memory load sits inside the frame loop
+// at n <= 1024 (twiddles and tables are in LDS), so nothing forces an early wait on them.
+template <int BYTES>
+__device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start, int T, int sidx, uint32_t (&lo)[16],
+                                 uint32_t (&hi)[BYTES == 8 ? 16 : 1])
+{
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint8_t *p = base + (start + rev4(e) * T + sidx) * BYTES;
+        if constexpr (BYTES == 2) {
+            lo[e] = *(const uint16_t *)p;
+        } else if constexpr (BYTES == 4) {
+            lo[e] = *(const uint32_t *)p;
+        } else {
+            // keep the two words of a sample in one 64-bit load result (an even-aligned register pair)
+            const unsigned long long w = *(const unsigned long long *)p;
+            lo[e] = (uint32_t)w;
+            hi[e] = (uint32_t)(w >> 32);
+        }
+    }
+}
+
+template <int FMT, int NHI>
+__device__ inline void decode_frame(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI], const double (&win)[16], double (&re)[16],
+                                    double (&im)[16])
+{
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        double vi, vq;
+        spfmt::decode_raw<FMT>(lo[e], hi[NHI == 16 ? e : 0], vi, vq);
+        re[e] = win[e] * vi;                                                   // worker.js:73-74
+        im[e] = win[e] * vq;
+    }
+}
+
 // Diagnostic build only (make STAMPS=1): per-phase s_memtime totals of wave 0 of every workgroup go to a.stamps.  The stamp's
 // own s_waitcnt drains outstanding LDS/SMEM operations, so such a build shows SHARES of a frame, never a valid run time.
 #ifdef SP_STAMPS
@@ -251,7 +294,7 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
 #define SP_STAMP(k) do { } while (0)
 #endif
 
-template <int LOG2N, bool CH>
+template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                          const int group_frames, const int groups)
 {
@@ -319,12 +362,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         }
     }
 
-    // taper coefficients of this thread's 16 samples stay in registers for the whole launch
-    double win[16];
-    {
+    // taper: in LDS for n <= 1024 (read per frame), in registers for the whole launch otherwise
+    constexpr bool WIN_LDS = lds_win_in_lds(N);
+    double *s_win = (double *)(smem + lay.off_win);
+    const double *const wbase = s_win + (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    double win_reg[WIN_LDS ? 1 : 16];
+    if constexpr (WIN_LDS) {
+        for (int i = tid; i < N; i += kLdsThreads) s_win[i] = a.window[i];
+    } else {
         const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
 #pragma unroll
-        for (int e = 0; e < 16; e++) win[e] = a.window[rev4(e) * T + sidx];
+        for (int e = 0; e < 16; e++) win_reg[e] = a.window[rev4(e) * T + sidx];
     }
     __syncthreads();
 
@@ -345,9 +393,24 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     const int chunk = (groups + 7) >> 3;
     const int g_end = min(groups, (xcd + 1) * chunk);
 
+    // register prefetch is used for the common sample widths when every frame lies inside the buffer
+    // (PFB is chosen by the host: frames inside the buffer and 2-, 4- or 8-byte samples)
+    constexpr bool PF = PFB != 0;
+    const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    const int rounds = group_frames / FPB;
+    uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
+    auto request = [&](int xq) {
+        if constexpr (PF) {
+        const int xc = xq < a.width ? xq : a.width - 1;
+        const int64_t st = frame_start(a.stride, xc);
+        issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi);
+        }
+    };
+    if (PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
+
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = g * group_frames;
-        for (int r = 0; r < group_frames / FPB; r++) {
+        for (int r = 0; r < rounds; r++) {
             const int fr = r * FPB + fs;            // frame within the group
             const int xr = x0 + fr;
             const bool live = xr < a.width;
@@ -355,18 +418,34 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             const int64_t start = frame_start(a.stride, x);
             SP_STAMP(0);   // loop control
 
+            double re[16], im[16];
+            double win[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
+            // the frame this slot processes next
+            const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
+            if constexpr (PF) {
+                if constexpr (PFB == 2) {
+                    if (format == SP_FMT_CU8) decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
+                    else decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
+                } else if constexpr (PFB == 4) {
+                    if (format == SP_FMT_CU16) decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im);
+                    else decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im);
+                } else {
+                    if (format == SP_FMT_CU32) decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im);
+                    else if (format == SP_FMT_CS32) decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im);
+                    else decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im);
+                }
+                if (xn >= 0) request(xn);           // in flight during this frame's butterflies
+            } else {
             // Touch the cache lines of the frame this slot processes next, so that its loads hit L2 instead of HBM.
             asm volatile("" ::"v"(pf_word));   // the previous touch has long landed; this only keeps the load alive
-            if (a.in_bounds) {
-                const int xn = (r + 1 < group_frames / FPB) ? xr + FPB : (g + per_xcd) * group_frames + fs;
+            if (a.in_bounds && xn >= 0 && xn < a.width) {
                 const int lines = (N * a.sample_width + 127) >> 7;
-                if (xn < a.width) {
-                    const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
-                    for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
-                }
+                const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
+                for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
             }
 
-            double re[16], im[16];
             switch (format) {
 #define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im); break;
                 SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CU8) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12)
@@ -374,6 +453,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 SP_CASE(SP_FMT_CU64) SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32)
 #undef SP_CASE
             default: load_frame<SP_FMT_CF64>(a, view, start, tl, T, LOG2N, win, re, im); break;
+            }
             }
 
             // ---- DFT: register passes with LDS re-distribution in between ---------------------------------
@@ -457,45 +537,49 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // the guess + 1; one comparison against the exact edge decides (edges: sp_host.h Thresholds).
             double mn = spjs::inf(), mx = 0.0;
             unsigned char *trow = s_tile + fr * tile_pitch;
-            double abs2[16];
-            int gc[16], lc[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                abs2[e] = re[e] * re[e] + im[e] * im[e];                           // worker.js:92
-                mn = min_nn(mn, abs2[e]);
-                mx = max_nn(mx, abs2[e]);
-                int ex;
-                const double mant = frexp(abs2[e], &ex);
-                const float l2 = (float)ex + __log2f((float)mant);
-                // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
-                gc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
-                lc[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
-            }
-            SP_STAMP(7);   // abs2 + first guesses
-            double ge[16], ce[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                ge[e] = s_gedge[gc[e] + 1];
-                ce[e] = s_cbedge[lc[e] + 1];
-            }
+            // Two halves of 8 bins keep the epilogue's temporaries (|X|^2, guesses, edges) at 64 VGPRs instead of 128.
             // Histograms without branches: values that are counted in per-lane registers (clipped colour indices, the end
             // bins of the centi-bel histogram) and values that are not counted at all (surplus frames, dropped keys) send
             // their LDS atomic to a per-lane trash word instead of serialising on one hot address.
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int gr = gc[e] + (abs2[e] >= ge[e] ? 1 : 0);
-                const int lv = lc[e] + (abs2[e] >= ce[e] ? 1 : 0);
-                // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0                worker.js:105
-                const bool special = !(abs2[e] > 0.0) || abs2[e] == spjs::inf();
-                trow[tl + e * T] = (unsigned char)gr;
-                const bool g0 = gr == 0, gm = gr == cmax;
-                cnt_g0 += (live && g0) ? 1u : 0u;
-                cnt_gmax += (live && gm) ? 1u : 0u;
-                atomicAdd((g0 || gm || !live) ? trash : &s_chist[gr], 1u);
-                const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
-                cnt_cb0 += (live && special) ? 1u : 0u;
-                cnt_cb_last += (live && !special && l0) ? 1u : 0u;
-                atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
+            for (int h = 0; h < 2; h++) {
+                double abs2[8], ge[8], ce[8];
+                int gc[8], lc[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int e = h * 8 + k;
+                    abs2[k] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
+                    mn = min_nn(mn, abs2[k]);
+                    mx = max_nn(mx, abs2[k]);
+                    int ex;
+                    const double mant = frexp(abs2[k], &ex);
+                    const float l2 = (float)ex + __log2f((float)mant);
+                    // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
+                    gc[k] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
+                    lc[k] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    ge[k] = s_gedge[gc[k] + 1];
+                    ce[k] = s_cbedge[lc[k] + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int e = h * 8 + k;
+                    const int gr = gc[k] + (abs2[k] >= ge[k] ? 1 : 0);
+                    const int lv = lc[k] + (abs2[k] >= ce[k] ? 1 : 0);
+                    // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0            worker.js:105
+                    const bool special = !(abs2[k] > 0.0) || abs2[k] == spjs::inf();
+                    trow[tl + e * T] = (unsigned char)gr;
+                    const bool g0 = gr == 0, gm = gr == cmax;
+                    cnt_g0 += (live && g0) ? 1u : 0u;
+                    cnt_gmax += (live && gm) ? 1u : 0u;
+                    atomicAdd((g0 || gm || !live) ? trash : &s_chist[gr], 1u);
+                    const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
+                    cnt_cb0 += (live && special) ? 1u : 0u;
+                    cnt_cb_last += (live && !special && l0) ? 1u : 0u;
+                    atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
+                }
             }
             SP_STAMP(8);   // edge reads, compares, tile bytes, histogram atomics
             // frame min / max over its T threads
@@ -616,27 +700,32 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;
 
-#define SP_LAUNCH_CH(L, C)                                                                                               \
+#define SP_LAUNCH_V(L, C, P)                                                                                              \
     {                                                                                                                    \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            if (hipFuncSetAttribute((const void *)k_lds_r16<L, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) \
-                != hipSuccess)                                                                                           \
+            if (hipFuncSetAttribute((const void *)k_lds_r16<L, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                    160 * 1024) != hipSuccess)                                                           \
                 return SP_ERR_HIP;                                                                                       \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_lds_r16<L, C>), dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a,     \
+        hipLaunchKernelGGL((k_lds_r16<L, C, P>), dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a,  \
                            format, stage_tw, gf, groups);                                                                \
     }
+#define SP_LAUNCH_CH(L, C)                                                                                               \
+    if (prefetch == 8) SP_LAUNCH_V(L, C, 8) else if (prefetch == 4) SP_LAUNCH_V(L, C, 4) else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else SP_LAUNCH_V(L, C, 0)
 #define SP_LAUNCH(L)                                                                                                     \
     case L:                                                                                                              \
-        if (a.channel_mode) SP_LAUNCH_CH(L, true) else SP_LAUNCH_CH(L, false)                                            \
+        if (a.channel_mode) { SP_LAUNCH_CH(L, true) } else { SP_LAUNCH_CH(L, false) }                                    \
         break;
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
+    // next-frame register prefetch: frames inside the buffer, 2-, 4- or 8-byte samples
+    const int prefetch = (a.in_bounds && (a.sample_width == 2 || a.sample_width == 4 || a.sample_width == 8)) ? a.sample_width : 0;
     switch (a.levels) {
         SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8) SP_LAUNCH(9) SP_LAUNCH(10) SP_LAUNCH(11) SP_LAUNCH(12) SP_LAUNCH(13)
     default: return SP_ERR_UNSUPPORTED;
     }
+#undef SP_LAUNCH_V
 #undef SP_LAUNCH_CH
 #undef SP_LAUNCH
     return SP_OK;
