@@ -176,6 +176,11 @@ def main():
     frames_per_s = world * W * args.steps / dt
     hsum = int(hists[:len(lut)].sum().item())
 
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.config)
+    if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed)
+        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+
     if rank == 0:
         out = {
             "metric": "STFT frames/sec (N=1024 cf32) + IQ MSamples/s end-to-end to RGBA" if args.config == "cfg2"
@@ -189,7 +194,7 @@ def main():
                        "generator": "trinoise seed=0x%08X step=%d gshift=%d amp=%g namp=%g" % (GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])},
             "msamples_per_s": frames_per_s * stride_eff / 1e6,
             "kernel": plan.kernel_name(),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
                          "frac_of_copy_ceiling_6290": achieved / 6290.0},
             "checks": {"c_hist_sum": hsum, "expected": world * W * n},

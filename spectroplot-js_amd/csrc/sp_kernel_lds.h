@@ -623,28 +623,44 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
                 const int quads = group_frames / 4;                 // frame quads per row
                 const int items = (N / 4) * quads;
-                for (int it = tid; it < items; it += kLdsThreads) {
-                    const int fq = it % quads, bq = it / quads;
-                    const int f0 = fq * 4, i0 = bq * 4;
-                    uint32_t gb[4];
+                // two items per thread and iteration: all tile reads first, then the LUT reads, then the stores, so the
+                // LDS latencies of the write-out overlap instead of adding up
+                for (int it0 = tid; it0 < items; it0 += 2 * kLdsThreads) {
+                    uint32_t gb[2][4];
+                    int i0v[2], xav[2];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) gb[k] = *(const uint32_t *)(s_tile + (f0 + k) * tile_pitch + i0);
-                    const int xa = x0 + f0;
-                    if (xa >= a.width) continue;
+                    for (int u = 0; u < 2; u++) {
+                        const int it = it0 + u * kLdsThreads;
+                        const int itc = it < items ? it : it0;
+                        const int fq = itc % quads, bq = itc / quads;
+                        i0v[u] = bq * 4;
+                        xav[u] = it < items ? x0 + fq * 4 : a.width;      // past the image: nothing is stored
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int i = i0 + j;
-                        const int y = (N / 2 - i) & (N - 1);
-                        uint32_t px[4];
+                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
+                    }
+                    uint32_t px[2][4][4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) px[k] = s_lut[(gb[k] >> (8 * j)) & 0xff];
-                        uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
-                        if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
-                            *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
-                        } else {
+                    for (int u = 0; u < 2; u++)
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (xa + k < a.width) ((uint32_t *)dst)[k] = px[k];
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int xa = xav[u];
+                        if (xa >= a.width) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int i = i0v[u] + j;
+                            const int y = (N / 2 - i) & (N - 1);
+                            uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                                *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
+                            }
                         }
                     }
                 }
