@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the RGBA strips to rank 0")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
+    ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     args = ap.parse_args()
@@ -90,11 +92,16 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    if args.oversubscribe:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     fmt, lg, n, window, cmap, frames, desc = CONFIGS[args.config]
     S = 1 << lg
@@ -103,7 +110,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     ctx = pkg.Context(local_rank)
-    stream = torch.cuda.current_stream()
+    # one explicit stream for torch fills, the library's kernels and the collectives (the null stream's handle is 0, which
+    # sp_context_set_stream reads as "use your own stream")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     win, weight = pkg.window(window, n)
     lut = load_cmap(cmap)
@@ -117,18 +127,29 @@ def main():
     gauges = torch.empty(3 * W, dtype=torch.uint8, device=dev)
     hists = torch.zeros(len(lut) + 1000, dtype=torch.int64, device=dev)
     minmax = torch.zeros(2, dtype=torch.float64, device=dev)
-    neg = torch.tensor([-1.0, 1.0], dtype=torch.float64, device=dev)
+
+    P = len(lut) + 1000 + 2
+    payload = torch.zeros(P, dtype=torch.int64, device=dev)          # [c_hist | cB_hist | dBfs_min, dBfs_max as f64 bits]
+    gathered = torch.zeros(world * P, dtype=torch.int64, device=dev) if world > 1 else None
+    merged = {}
 
     def step():
         hists.zero_()
         plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
         if dist is not None:
-            # the caller's merge of the side outputs (lib/spectroplot.js:1229-1238): sums and min / max
-            dist.all_reduce(hists, op=dist.ReduceOp.SUM)
-            mm = minmax * neg                  # (-min, max) so that one MAX all-reduce serves both
-            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
-            minmax.copy_(mm * neg)
+            # the caller's merge of the side outputs (lib/spectroplot.js:1229-1238) as ONE collective: every rank gathers
+            # all ranks' histograms and dBfs ranges (10 KB each) and reduces them locally (sums, min, max)
+            payload[:P - 2] = hists
+            payload[P - 2:] = minmax.view(torch.int64)
+            dist.all_gather_into_tensor(gathered, payload)
+            g = gathered.view(world, P)
+            merged["hists"] = g[:, :P - 2].sum(dim=0)
+            mm = g[:, P - 2:].contiguous().view(torch.float64).view(world, 2)
+            merged["min"] = mm[:, 0].min()
+            merged["max"] = mm[:, 1].max()
+        else:
+            merged["hists"] = hists
 
     def sync():
         if dist is not None:
@@ -143,6 +164,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    hsum = int(merged["hists"][:len(lut)].sum().item())       # all slices after the merge
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,7 +196,6 @@ def main():
     algo_bytes = bytes_per_frame * W
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     frames_per_s = world * W * args.steps / dt
-    hsum = int(hists[:len(lut)].sum().item())
 
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.config)

@@ -51,13 +51,13 @@ __host__ __device__ inline int lds_group_frames(int n, int want)
     return f;
 }
 
-// Stages 5..kLdsTwMaxStage keep their twiddle tables in LDS (table of stage s = entries [2^(s-1), 2^s) of stage_tw);
-// stages 1-4 have lane-uniform twiddles (scalar loads) and stages above kLdsTwMaxStage read HBM/L2.
+// Stages 1..kLdsTwMaxStage keep their twiddle tables in LDS (table of stage s = entries [2^(s-1), 2^s) of stage_tw);
+// stages 1-4 have lane-uniform twiddles (broadcast LDS reads: keeping them in SGPRs cost ~100 spilled SGPRs and the
+// v_readlane traffic that goes with them) and stages above kLdsTwMaxStage read HBM/L2.
 constexpr int kLdsTwMaxStage = 10;
 __host__ __device__ inline constexpr int lds_tw_entries(int n)
 {
-    const int top = n < (1 << kLdsTwMaxStage) ? n : (1 << kLdsTwMaxStage);
-    return top > 16 ? top - 16 : 0;
+    return n < (1 << kLdsTwMaxStage) ? n : (1 << kLdsTwMaxStage);   // entries [0, top): stage s at [2^(s-1), 2^s)
 }
 
 __host__ __device__ inline constexpr bool lds_win_in_lds(int n) { return n <= 1024; }
@@ -108,7 +108,7 @@ __device__ inline int pad_idx(int p) { return p + (p >> 4); }
 __device__ inline constexpr int win_off(int e, int ws) { return (e << ws) + ((e << ws) >> 4); }
 
 // One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
-// tw_lds: LDS copy of stage_tw[16 ..), tw_glb: the full table in HBM/L2.
+// tw_lds: LDS copy of stage_tw[0 .. min(n, 1024)), tw_glb: the full table in HBM/L2.
 template <int WS, int S0, int S1>
 __device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ tw_lds,
                                 const double2 *__restrict__ tw_glb)
@@ -126,7 +126,7 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, cons
             const int e1 = e0 | (1 << u);
             // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
             const int m = tl_low | ((e0 & ((1 << u) - 1)) << WS);
-            const double2 w = (s >= 5 && s <= kLdsTwMaxStage) ? tw_lds[half - 16 + m] : tw_glb[half + m];
+            const double2 w = s <= kLdsTwMaxStage ? tw_lds[half + m] : tw_glb[half + m];
             const double c = w.x, sn = w.y;
             const double rl = re[e1], il = im[e1];
             const double tpre = rl * c + il * sn;          // fft_nayuki.js:80
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #pragma unroll
         for (int k = 0; k < TWK; k++) {
             const int i = tid + k * kLdsThreads;
-            tw_r[k] = i < NTW ? stage_tw[16 + i] : make_double2(0.0, 0.0);
+            tw_r[k] = i < NTW ? stage_tw[i] : make_double2(0.0, 0.0);
         }
         const double ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;            // lut_len <= 256 < kLdsThreads
         const unsigned int lut_r = tid < a.lut_len ? a.lut_rgba[tid] : 0u;
@@ -579,6 +579,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                     cnt_cb0 += (live && special) ? 1u : 0u;
                     cnt_cb_last += (live && !special && l0) ? 1u : 0u;
                     atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
+                    // one bin at a time: interleaving the eight bins keeps ~50 compare masks alive and spills SGPRs
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             SP_STAMP(8);   // edge reads, compares, tile bytes, histogram atomics

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kWaveThreads) void k_wave_r16(const FrameArgs a, co
 #pragma unroll
         for (int k = 0; k < TWK; k++) {
             const int i = tid + k * kWaveThreads;
-            tw_r[k] = i < NTW ? stage_tw[16 + i] : make_double2(0.0, 0.0);
+            tw_r[k] = i < NTW ? stage_tw[i] : make_double2(0.0, 0.0);
         }
         const double ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;
         const unsigned int lut_r = tid < a.lut_len ? a.lut_rgba[tid] : 0u;
