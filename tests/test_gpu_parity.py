@@ -214,3 +214,97 @@ def test_full_size_config2_sampled_frames(pkg, ctx, golden):
     for p in ptrs + [d_in]:
         ctx.free(p)
     plan.close()
+
+
+def _random_cases(count, seed):
+    rs = np.random.RandomState(seed)
+    fmts = ["CU4", "CS4", "CU8", "CS8", "CU12", "CS12", "CU16", "CS16", "CU32", "CS32", "CU64", "CS64", "CF32", "CF64"]
+    wins = ["rectangular", "bartlett", "hamming", "hann", "blackman", "blackmanHarris"]
+    out = []
+    for i in range(count):
+        fmt = fmts[rs.randint(len(fmts))]
+        n = 1 << rs.randint(1, 14)                      # 2 .. 8192 (scratch kernel below 64)
+        frames = int(rs.randint(1, 80 if n >= 2048 else 300))
+        mode = rs.randint(4)                            # hop = n, fractional, overlap, sparse
+        if mode == 0:
+            samples = n * frames
+        elif mode == 1:
+            samples = n * frames + int(rs.randint(1, n))
+        elif mode == 2:
+            samples = n + (frames - 1) * max(1, n // int(rs.randint(2, 9))) + int(rs.randint(0, 3))
+        else:
+            samples = n * frames * int(rs.randint(2, 5)) + int(rs.randint(0, 7))
+        samples = min(samples, 1 << 19)
+        if samples < n:
+            samples = n
+        lut_len = int(rs.choice([2, 3, 17, 64, 255, 256, 256, 256, 300]))
+        out.append(dict(fmt=fmt, n=n, width=frames, samples=samples, win=wins[rs.randint(len(wins))], gain=float(rs.randint(-10, 60)),
+                        rng=float(rs.choice([6, 12, 30, 30, 45.5, 90, 120])), ch=bool(rs.randint(2)), wf=bool(rs.randint(2)), lut_len=lut_len,
+                        seed=int(rs.randint(1 << 30)), amp=float(rs.choice([0.05, 0.5, 0.9])), kind=str(rs.choice(["trinoise", "trinoise", "bytes"]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(60, 20261002), ids=lambda c: "%s_n%d_w%d_%s" % (c["fmt"], c["n"], c["width"], "lr" if c["ch"] else "iq"))
+def test_random_requests_against_oracle(pkg, ctx, case):
+    """Seeded random requests (all formats, n = 2 .. 8192, every stride regime, both layouts, L/R split, odd LUT lengths)
+    through sp_render against the C oracle: every output bit-exact."""
+    c = case
+    kind = c["kind"] if not c["fmt"].startswith("CF") else "trinoise"
+    gen = {"kind": kind, "seed": c["seed"], "step": 4099, "gshift": 9, "amp": c["amp"], "namp": 0.02}
+    data = siggen.generate(c["fmt"], gen, c["samples"])
+    win, weight = pyoracle.window(c["win"], c["n"])
+    i = np.arange(c["lut_len"])
+    lut = np.stack([(i * 5) & 255, (i * 11 + 3) & 255, (255 - i) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(c["fmt"], data, c["n"], win, 1.0 / weight, c["gain"], c["rng"], lut, c["width"], c["ch"], c["wf"])
+    got = ctx.render(c["fmt"], data, c["n"], win, 1.0 / weight, c["gain"], c["rng"], lut, c["width"], c["ch"], c["wf"])
+    for k in ("rgba", "gauge_mins", "gauge_maxs", "gauge_amps"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["c_hist"].astype(np.int64), want["c_hist"])
+    assert np.array_equal(got["cB_hist"].astype(np.int64), want["cB_hist"])
+    for k in ("dBfs_min", "dBfs_max"):
+        a, b = np.float64(got[k]), np.float64(want[k])
+        assert (a != a and b != b) or a.view(np.uint64) == b.view(np.uint64), k
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, format, log2 samples, n, frames (None = S/n), window
+    ("config3_cs16_n2048", "CS16", 25, 2048, None, "hann"),
+    ("config4_slice_cu8_n1024", "CU8", 26, 1024, None, "blackmanHarris"),
+    ("config5_cs12_n8192_zoom8", "CS12", 23, 8192, (1 << 23) // 8192 * 8, "blackmanHarris"),
+], ids=lambda c: c[0])
+def test_baseline_config_shapes_sampled_frames(pkg, ctx, golden, cfg):
+    """The other BASELINE.json configurations (length scaled down, shape kept: format, n, hop / 8x overlap, window) on
+    device-generated input: histogram totals plus bit-exact comparison of sampled frames (image column, gauges) with the
+    oracle, which renders each sampled frame from its own n samples (frames are independent given their start)."""
+    name, fmt, lg, n, frames, wname = cfg
+    S = 1 << lg
+    sw = siggen.SAMPLE_WIDTH[fmt]
+    W = frames or S // n
+    gen = dict(seed=0x5EED0001, step=7321, gshift=11, amp=0.5, namp=0.02)
+    win, weight = pyoracle.window(wname, n)
+    lut = golden.lut("cube1", force_ends=True)
+    d_in = ctx.alloc(S * sw)
+    ctx.synth_trinoise(d_in, fmt, 0, S, gen["seed"], gen["step"], gen["gshift"], gen["amp"], gen["namp"])
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+    sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+    ptrs = [ctx.alloc(s) for s in sizes]
+    for p, s in zip(ptrs, sizes):
+        ctx.memset(p, 0, s)
+    plan.execute(d_in, S * sw, W, *ptrs)
+    ctx.synchronize()
+    rgba = ctx.download(ptrs[0], sizes[0]).reshape(n, W, 4)
+    c_hist = ctx.download(ptrs[4], 8 * 256, np.uint64)
+    gmin, gmax, gamp = (ctx.download(ptrs[i], W) for i in (1, 2, 3))
+    assert int(c_hist.sum()) == W * n
+    assert (rgba[:, ::97, 3] == 255).all()
+    stride = (S - n) / (W - 1)
+    rs = np.random.RandomState(11)
+    for x in list(rs.randint(0, W, size=10)) + [0, W - 1]:
+        start = int(0.5 + stride * int(x))                      # ~~(0.5 + stride * x), positive here
+        frame = siggen.generate(fmt, dict(kind="trinoise", **gen), n, t0=start)
+        o = pyoracle.render(fmt, frame, n, win, 1.0 / weight, 6.0, 30.0, lut, 1)
+        assert np.array_equal(rgba[:, x, :].reshape(-1), o["rgba"]), (name, x)
+        assert gmin[x] == o["gauge_mins"][0] and gmax[x] == o["gauge_maxs"][0] and gamp[x] == o["gauge_amps"][0], (name, x)
+    for p in ptrs + [d_in]:
+        ctx.free(p)
+    plan.close()
