@@ -277,6 +277,26 @@ const run = async () => {
         fs.writeFileSync(path.join(outdir, 'math_trig.bin'), Buffer.concat([Buffer.from(ts.buffer), Buffer.from(cs.buffer), Buffer.from(ss.buffer)]))
     }
 
+    // ---- file-name parsing and key lookup KAT (lib/parseFreqRate.js, lib/utils.js lookup) -----------------------------
+    {
+        const saved = console.log
+        console.log = () => {}                      // parseFreqRate logs when it strips a path
+        const P = await import('./lib/parseFreqRate.js')
+        // utils.js touches `document` / DOMParser only inside functions, lookup itself is pure
+        const U = await import('./lib/utils.js')
+        const names = spec.parse_kat.names
+        const parsed = names.map(nm => ({ name: nm, format: P.parseFormat(nm), fr: P.parseFreqRate(nm) }))
+        const table = {}
+        for (const k of Object.keys(windows)) table[k] = k
+        const lookups = spec.parse_kat.window_keys.map(k => ({ key: k, hit: U.lookup(table, k) }))
+        const ctable = {}
+        for (const k of Object.keys(cmaps)) ctable[k] = k
+        const clookups = spec.parse_kat.cmap_keys.map(k => ({ key: k, hit: U.lookup(ctable, k) }))
+        console.log = saved
+        fs.writeFileSync(path.join(outdir, 'parse.json'), JSON.stringify({ parsed, lookups, clookups, cmap_key_order: Object.keys(cmaps),
+            window_key_order: Object.keys(windows) }, null, 0))
+    }
+
     fs.writeFileSync(path.join(outdir, 'provenance.json'), JSON.stringify({
         generated_by: 'oracle/gen_golden.js + oracle/ref_harness.mjs',
         reference: 'triq-org/spectroplot-js lib/worker.js (v1.2.1, /root/reference)',

@@ -2,4 +2,5 @@
 /** Node entry point: `const { HipWorker } = require('spectroplot-js_amd/js')` then `new Spectroplot({workerOrUrl: HipWorker, ...})`. */
 const { HipWorker, packLut } = require('./hip_worker.js')
 const { renderSliced } = require('./render_file.js')
-module.exports = { HipWorker, packLut, renderSliced }
+const params = require('./params.js')
+module.exports = Object.assign({ HipWorker, packLut, renderSliced }, params)

@@ -23,6 +23,12 @@ def test_addon_loads_and_host_helpers_match_reference_kats():
     assert "addon cpu checks ok" in out.stdout
 
 
+def test_caller_side_parameter_helpers_match_reference():
+    out = _node("check_params.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "params checks ok" in out.stdout
+
+
 @pytest.mark.gpu
 def test_hip_worker_reproduces_golden_vectors():
     out = _node("check_hip_worker.js")
