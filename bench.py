@@ -68,8 +68,8 @@ def cpu_baseline(fmt, n, window, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the RGBA strips to rank 0")
@@ -134,7 +134,6 @@ def main():
     merged = {}
 
     def step():
-        hists.zero_()
         plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
         if dist is not None:
@@ -173,10 +172,11 @@ def main():
     # dominant kernel: live HIP-event timing of the frame-loop kernel on its stream, outside the timed region
     ctx.enable_timing(True)
     kms = []
-    for _ in range(max(10, min(args.steps, 50))):
-        hists.zero_()
-        plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
-                     hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
+    for _ in range(10):
+        # a short back-to-back batch, as in the timed region; the events bracket the batch's last frame-loop kernel
+        for _ in range(max(2, min(args.steps, 20))):
+            plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                         hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
         torch.cuda.synchronize()
         kms.append(ctx.last_kernel_ms())
     ctx.enable_timing(False)

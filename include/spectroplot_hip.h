@@ -133,12 +133,13 @@ void sp_plan_destroy(sp_plan *plan);
 /*
  * The frame loop on device-resident operands, asynchronous on the context's stream.
  * d_bytes: device pointer to the raw capture (nbytes bytes, 16-byte aligned); reply: device pointers.
- * Histograms are accumulated into reply->c_hist / cb_hist.
+ * Every output of the reply is overwritten, histograms included: a reply holds the counts of its own request, as the
+ * reference's worker returns fresh arrays (lib/worker.js:40-41); the caller sums the slices (lib/spectroplot.js:1229-1238).
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
-/* Name of the kernel variant sp_plan_execute launches ("wave_r16+colorize", "lds_r16", "scratch_radix2"). */
+/* Name of the kernel variant sp_plan_execute launches ("lds_r16", "scratch_radix2"). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
-/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16, 3 wave_r16. */
+/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16. */
 int sp_plan_force_kernel(sp_plan *plan, int32_t which);
 
 /* Device memory helpers so that non-HIP hosts (Node, ctypes) can keep operands resident. */

@@ -34,6 +34,10 @@ class _Reply(C.Structure):
 
 
 def lib_path():
+    # SP_LIB_VARIANT=<name> loads lib/variants/<name>.so instead (kernel experiments built with other compile-time options)
+    v = os.environ.get("SP_LIB_VARIANT")
+    if v:
+        return os.path.join(_HERE, "lib", "variants", v + ".so")
     return os.path.join(_HERE, "lib", "libspectroplot_hip.so")
 
 
@@ -262,7 +266,7 @@ class Plan:
         return self.ctx.lib.L.sp_plan_kernel_name(self.h).decode()
 
     def force_kernel(self, which):
-        self.ctx._chk(self.ctx.lib.L.sp_plan_force_kernel(self.h, {"auto": 0, "scratch": 1, "lds": 2, "wave": 3}[which]))
+        self.ctx._chk(self.ctx.lib.L.sp_plan_force_kernel(self.h, {"auto": 0, "scratch": 1, "lds": 2}[which]))
 
     def execute(self, d_bytes, nbytes, width, rgba=0, gauge_mins=0, gauge_maxs=0, gauge_amps=0, c_hist=0, cb_hist=0, dbfs_minmax=0):
         """All pointer arguments are device addresses (ints); 0 skips that output. Asynchronous on the context's stream."""

@@ -16,7 +16,6 @@
 #include "../../include/spectroplot_hip.h"
 #include "sp_host.h"
 #include "sp_kernel_lds.h"
-#include "sp_kernel_wave.h"
 #include "sp_kernel_scratch.h"
 #include "sp_synth.h"
 
@@ -57,11 +56,12 @@ struct sp_context {
     int cu_count = 256;
     // workspace of the frame loop
     DeviceBuffer frame_minmax;   // 2 * width doubles
-    DeviceBuffer partial;        // finish-kernel partials
+    DeviceBuffer partial;        // finish-kernel state: ticket, {min,max} accumulator, histogram accumulators
     DeviceBuffer scratch;        // scratch kernel slabs
     // staging for sp_render (host-buffer entry point)
-    DeviceBuffer in_bytes, out_rgba, render_small, hist_dummy;
+    DeviceBuffer in_bytes, out_rgba, render_small;
     sp_plan *cached_plan = nullptr;
+    bool acc_dirty = false;      // a request failed between its two kernels: accumulators must be re-initialised
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -77,11 +77,12 @@ struct sp_plan {
     spfmt::Format fmt{};
     double block_norm_db = 0;
     float gray_a = 0, gray_b = 0, cb_a = 0, cb_b = 0;
+    bool edges_in_f32 = false;      // every colour / centi-bel edge lies in [2^-100, 2^100]: the f32 first guess is enough
     DeviceBuffer tables;            // one allocation, carved below
     const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
     const uint32_t *d_lut = nullptr;
     const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
-    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds, 3 wave
+    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds
 };
 
 namespace {
@@ -238,7 +239,6 @@ extern "C" void sp_context_destroy(sp_context *ctx)
     ctx->in_bytes.release();
     ctx->out_rgba.release();
     ctx->render_small.release();
-    ctx->hist_dummy.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -372,6 +372,9 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
     p->gray_b = th.gray_b;
     p->cb_a = th.cb_a;
     p->cb_b = th.cb_b;
+    p->edges_in_f32 = true;
+    for (int g = 1; g < L; g++) p->edges_in_f32 &= th.gray_edge[(size_t)g] >= 0x1p-100 && th.gray_edge[(size_t)g] <= 0x1p100;
+    for (int j = 1; j <= SP_CB_HIST_SIZE; j++) p->edges_in_f32 &= th.cb_edge[(size_t)j] >= 0x1p-100 && th.cb_edge[(size_t)j] <= 0x1p100;
     std::vector<uint32_t> lut32((size_t)L);
     for (int i = 0; i < L; i++)
         lut32[(size_t)i] = (uint32_t)p->lut[3 * (size_t)i] | ((uint32_t)p->lut[3 * (size_t)i + 1] << 8)
@@ -442,30 +445,25 @@ extern "C" void sp_plan_destroy(sp_plan *plan)
 static bool plan_lds_capable(const sp_plan *plan)
 {
     return spk::lds_kernel_supports(plan->req.n) && plan->req.lut_len >= 2 && plan->req.lut_len <= spk::kLdsMaxLut
-           && plan->gray_b <= spk::kLdsMaxGrayB;
+           && plan->gray_b <= spk::kLdsMaxGrayB && plan->edges_in_f32;
 }
 
-static bool plan_wave_capable(const sp_plan *plan) { return plan_lds_capable(plan) && spk::wave_kernel_supports(plan->req.n); }
-
-// 1 = scratch_radix2, 2 = lds_r16, 3 = wave_r16 + colorize
+// 1 = scratch_radix2, 2 = lds_r16
 static int plan_kernel(const sp_plan *plan)
 {
     if (plan->force_kernel) return plan->force_kernel;
     static const int env_kernel = getenv("SP_FORCE_KERNEL") ? atoi(getenv("SP_FORCE_KERNEL")) : 0;   // experiments only
-    if (env_kernel == 3 && plan_wave_capable(plan)) return 3;
     if (env_kernel == 2 && plan_lds_capable(plan)) return 2;
     if (env_kernel == 1) return 1;
-    // The fused LDS kernel is the default.  The two-kernel variant (3) measured no faster on MI355X (its extra waves
-    // are spent on LDS / f64 issue contention, DESIGN.md "What was tried"); it stays selectable for comparison.
+    // The fused LDS kernel is the default; the scratch kernel covers every request the LDS kernel does not.
     if (plan_lds_capable(plan)) return 2;
     return 1;
 }
 
 extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
 {
-    if (!plan || which < 0 || which > 3) return SP_ERR_INVALID_ARG;
+    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
     if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this request");
-    if (which == 3 && !plan_wave_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "wave kernel does not cover this request");
     plan->force_kernel = which;
     return SP_OK;
 }
@@ -474,7 +472,6 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 {
     if (!plan) return "";
     switch (plan_kernel(plan)) {
-    case 3: return "wave_r16";
     case 2: return "lds_r16";
     default: return "scratch_radix2";
     }
@@ -498,6 +495,8 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
 
     if (width == 0) {
         // nothing to draw; the reply keeps the loop's initial values (worker.js:35-36)
+        if (out->c_hist) SP_HIP(ctx, hipMemsetAsync(out->c_hist, 0, (size_t)plan->req.lut_len * sizeof(uint64_t), s));
+        if (out->cb_hist) SP_HIP(ctx, hipMemsetAsync(out->cb_hist, 0, SP_CB_HIST_SIZE * sizeof(uint64_t), s));
         if (out->dbfs_minmax) {
             static const double init[2] = {0.0, -200.0};
             SP_HIP(ctx, hipMemcpyAsync(out->dbfs_minmax, init, sizeof init, hipMemcpyHostToDevice, s));
@@ -521,11 +520,24 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
 
     int rc = ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
-    const int finish_blocks = (width + spk::kFinishThreads - 1) / spk::kFinishThreads;
-    const bool fresh_partial = ctx->partial.cap < 2 * (size_t)finish_blocks * sizeof(double) + 64;
-    rc = ctx->partial.reserve(2 * (size_t)finish_blocks * sizeof(double) + 64);   // + the arrival ticket
+    int finish_blocks = 3 * ((width + spk::kFinishThreads - 1) / spk::kFinishThreads);   // three roles per 256 frames
+    {
+        const int bins = plan->req.lut_len > SP_CB_HIST_SIZE ? plan->req.lut_len : SP_CB_HIST_SIZE;   // it also moves the histograms
+        const int hb = (bins + spk::kFinishThreads - 1) / spk::kFinishThreads;
+        if (finish_blocks < hb) finish_blocks = hb;
+    }
+    // [16,32) bit patterns of the extreme |X|^2 of a launch, [64, ...) colour and centi-bel histogram accumulators
+    const size_t acc_bytes = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
+    const bool fresh_partial = ctx->partial.cap < acc_bytes;
+    rc = ctx->partial.reserve(acc_bytes);
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
-    if (fresh_partial) SP_HIP(ctx, hipMemsetAsync(ctx->partial.p, 0, ctx->partial.cap, s));
+    if (fresh_partial || ctx->acc_dirty) {
+        static const unsigned long long mm_init[2] = {0x7ff0000000000000ull, 0ull};           // +inf, 0
+        SP_HIP(ctx, hipMemsetAsync(ctx->partial.p, 0, ctx->partial.cap, s));
+        SP_HIP(ctx, hipMemcpyAsync((char *)ctx->partial.p + 16, mm_init, sizeof mm_init, hipMemcpyHostToDevice, s));
+        SP_HIP(ctx, hipStreamSynchronize(s));
+    }
+    ctx->acc_dirty = true;   // until the finish kernel of this request has been queued
 
     spk::FrameArgs a{};
     a.bytes = (const uint8_t *)d_bytes;
@@ -579,24 +591,14 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     }
 #endif
 
-    // histograms are optional for the caller but the kernels always count: point them at scratch space if absent
-    DeviceBuffer &small = ctx->hist_dummy;
-    unsigned long long *c_hist = (unsigned long long *)out->c_hist, *cb_hist = (unsigned long long *)out->cb_hist;
-    if (!c_hist || !cb_hist) {
-        rc = small.reserve((SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(uint64_t));
-        if (rc) return fail(ctx, rc, "workspace: out of device memory");
-        if (!c_hist) c_hist = (unsigned long long *)small.p;
-        if (!cb_hist) cb_hist = (unsigned long long *)small.p + SP_MAX_LUT;
-    }
-    a.c_hist = c_hist;
-    a.cb_hist = cb_hist;
+    // the kernels count into the context's accumulators; the finish kernel moves the counts to the reply
+    a.mm_acc = (unsigned long long *)((char *)ctx->partial.p + 16);
+    a.c_hist = (unsigned long long *)((char *)ctx->partial.p + 64);
+    a.cb_hist = a.c_hist + SP_MAX_LUT;
 
     const int which = plan_kernel(plan);
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (which == 3) {
-        rc = spk::launch_wave(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
-        if (rc) return fail(ctx, rc, "wave kernel launch rejected the configuration");
-    } else if (which == 2) {
+    if (which == 2) {
         rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
         if (rc) return fail(ctx, rc, "LDS kernel launch rejected the configuration");
     } else {
@@ -636,11 +638,16 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     fa.gauge_mins = out->gauge_mins;
     fa.gauge_maxs = out->gauge_maxs;
     fa.gauge_amps = out->gauge_amps;
-    fa.partial = (double *)ctx->partial.p + 8;
-    fa.ticket = (unsigned int *)ctx->partial.p;
+    fa.mm_acc = a.mm_acc;
     fa.out_minmax = out->dbfs_minmax;
+    fa.lut_len = plan->req.lut_len;
+    fa.acc_c = a.c_hist;
+    fa.acc_cb = a.cb_hist;
+    fa.out_c = (unsigned long long *)out->c_hist;
+    fa.out_cb = (unsigned long long *)out->cb_hist;
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);
     SP_HIP(ctx, hipGetLastError());
+    ctx->acc_dirty = false;
     return SP_OK;
 }
 

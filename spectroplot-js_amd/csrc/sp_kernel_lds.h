@@ -29,7 +29,10 @@
 
 namespace spk {
 
-constexpr int kLdsThreads = 512;
+#ifndef SP_LDS_THREADS
+#define SP_LDS_THREADS 512
+#endif
+constexpr int kLdsThreads = SP_LDS_THREADS;
 constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
 constexpr int kLdsMaxLut = 256;      // colour indices travel through a byte tile
 constexpr float kLdsMaxGrayB = 2000.0f;   // first-guess slope bound that keeps the one-compare correction exact
@@ -78,7 +81,7 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_fr
     l.off_tw = o;     o += lds_tw_entries(n) * 16;     // per-stage twiddles of stages 5..10 (16-byte aligned)
     l.off_gedge = o;  o += lut_len * 8;
     l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
-    l.off_mm = o;     o += group_frames * 8 * 2 * 8;   // up to 8 wave partials per frame, {min,max}
+    l.off_mm = o;     o += group_frames * 2 * 8;       // per frame {min, max} of |X|^2 as bit patterns (LDS atomics)
     l.off_tile = o;   o += (l.tile_bytes + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
     l.off_chist = o;  o += lut_len * 4;
@@ -107,26 +110,46 @@ __device__ inline int pad_idx(int p) { return p + (p >> 4); }
 // constant, so every LDS access of an exchange is one base register plus an immediate offset
 __device__ inline constexpr int win_off(int e, int ws) { return (e << ws) + ((e << ws) >> 4); }
 
-// One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
-// tw_lds: LDS copy of stage_tw[0 .. min(n, 1024)), tw_glb: the full table in HBM/L2.
+// Twiddles of one register pass: stages S0..S1 inside window [WS, WS+4); stage s needs 2^(s-1-WS) of them per thread.
 template <int WS, int S0, int S1>
-__device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ tw_lds,
-                                const double2 *__restrict__ tw_glb)
+struct PassTw {
+    static constexpr int count = (1 << (S1 - WS)) - (1 << (S0 - 1 - WS));
+    double2 w[count];
+};
+
+// tw_lds: LDS copy of stage_tw[0 .. min(n, 1024)), tw_glb: the full table in HBM/L2.  Issued as one batch well before the
+// pass (ahead of the re-distribution that precedes it), so no butterfly waits on an LDS round trip.
+template <int WS, int S0, int S1>
+__device__ inline void load_pass_tw(PassTw<WS, S0, S1> &t, int tl, const double2 *__restrict__ tw_lds, const double2 *__restrict__ tw_glb)
 {
+    const int tl_low = tl & ((1 << WS) - 1);
+    int k = 0;
 #pragma unroll
     for (int s = S0; s <= S1; s++) {
-        // keep the twiddle reads of a stage from being hoisted above the previous stage: at most 8 (x4 VGPRs) are live
-        if (WS > 0 && s > S0) asm volatile("" ::: "memory");
-        const int u = (s - 1) - WS;          // bit of the register index toggled by this stage
+        const int u = (s - 1) - WS;
         const int half = 1 << (s - 1);
-        const int tl_low = tl & ((1 << WS) - 1);
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) {
+            // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
+            const int m = tl_low | (j << WS);
+            t.w[k++] = s <= kLdsTwMaxStage ? tw_lds[half + m] : tw_glb[half + m];
+        }
+    }
+}
+
+// One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
+template <int WS, int S0, int S1>
+__device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw<WS, S0, S1> &t)
+{
+    int base = 0;
+#pragma unroll
+    for (int s = S0; s <= S1; s++) {
+        const int u = (s - 1) - WS;          // bit of the register index toggled by this stage
 #pragma unroll
         for (int e0 = 0; e0 < 16; e0++) {
             if (e0 & (1 << u)) continue;
             const int e1 = e0 | (1 << u);
-            // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
-            const int m = tl_low | ((e0 & ((1 << u) - 1)) << WS);
-            const double2 w = s <= kLdsTwMaxStage ? tw_lds[half + m] : tw_glb[half + m];
+            const double2 w = t.w[base + (e0 & ((1 << u) - 1))];
             const double c = w.x, sn = w.y;
             const double rl = re[e1], il = im[e1];
             const double tpre = rl * c + il * sn;          // fft_nayuki.js:80
@@ -137,6 +160,7 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], int tl, cons
             re[e0] = rj + tpre;
             im[e0] = ij + tpim;
         }
+        base += 1 << u;
     }
 }
 
@@ -305,13 +329,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
     constexpr int NPASS = (LOG2N + 3) / 4;
 
+    if (a.dbg & 2048) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
     double *s_xch = (double *)smem;
     double2 *s_tw = (double2 *)(smem + lay.off_tw);
     double *s_gedge = (double *)(smem + lay.off_gedge);
     double *s_cbedge = (double *)(smem + lay.off_cbedge);
-    double *s_mm = (double *)(smem + lay.off_mm);
+    unsigned long long *s_mm = (unsigned long long *)(smem + lay.off_mm);
     unsigned char *s_tile = smem + lay.off_tile;
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
     unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);
@@ -374,7 +399,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #pragma unroll
         for (int e = 0; e < 16; e++) win_reg[e] = a.window[rev4(e) * T + sidx];
     }
+    if (tid < group_frames) {
+        s_mm[2 * tid] = 0x7ff0000000000000ull;
+        s_mm[2 * tid + 1] = 0ull;
+    }
     __syncthreads();
+    if (a.dbg & 1024) return;
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-    // clipped colour indices and the end bins of the centi-bel histogram are counted in per-lane registers
+    // clipped colour indices and the end bins of the centi-bel histogram are counted in per-wave (scalar) registers
     // (they dominate typical images and would serialise as same-address LDS atomics)
     unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
     const float gray_a = a.gray_a, gray_b = a.gray_b, cb_a = a.cb_a, cb_b = a.cb_b;
@@ -408,6 +438,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     };
     if (PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
 
+    unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = g * group_frames;
         for (int r = 0; r < rounds; r++) {
@@ -422,6 +453,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             double win[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
+            PassTw<0, 1, 4> tw0;
+            load_pass_tw(tw0, tl, s_tw, stage_tw);   // lane-uniform (broadcast reads), in flight during the decode
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
@@ -463,21 +496,25 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
             SP_STAMP(1);   // touch + input loads + decode + taper
-            fft_pass<0, 1, 4>(re, im, tl, s_tw, stage_tw);
+            fft_pass<0, 1, 4>(re, im, tw0);
             SP_STAMP(2);   // pass 0
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
+                PassTw<WS1, 5, E1> tw1;
+                load_pass_tw(tw1, tl, s_tw, tw);
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
                 SP_STAMP(3);   // exchange 1 (LDS)
-                fft_pass<WS1, 5, E1>(re, im, tl, s_tw, tw);
+                fft_pass<WS1, 5, E1>(re, im, tw1);
                 SP_STAMP(4);   // pass 1
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
+                    PassTw<WS2, 9, E2> tw2;
+                    load_pass_tw(tw2, tl, s_tw, tw);
                     if constexpr (LOG2N == 9 || LOG2N == 10) {
                         exchange_permlane<LOG2N>(re);      // no LDS: v_permlane16_swap / v_permlane32_swap
                         exchange_permlane<LOG2N>(im);
@@ -486,14 +523,16 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
                     }
                     SP_STAMP(5);   // exchange 2 (permlane or LDS)
-                    fft_pass<WS2, 9, E2>(re, im, tl, s_tw, tw);
+                    fft_pass<WS2, 9, E2>(re, im, tw2);
                     SP_STAMP(6);   // pass 2
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
+                        PassTw<WS3, 13, LOG2N> tw3;
+                        load_pass_tw(tw3, tl, s_tw, tw);
                         exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
                         exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
-                        fft_pass<WS3, 13, LOG2N>(re, im, tl, s_tw, tw);
+                        fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
                 }
             }
@@ -537,89 +576,100 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // the guess + 1; one comparison against the exact edge decides (edges: sp_host.h Thresholds).
             double mn = spjs::inf(), mx = 0.0;
             unsigned char *trow = s_tile + fr * tile_pitch;
+            // Surplus slots (recomputed last frame) skip the whole epilogue: one branch per frame instead of a mask per bin.
             // Two halves of 8 bins keep the epilogue's temporaries (|X|^2, guesses, edges) at 64 VGPRs instead of 128.
-            // Histograms without branches: values that are counted in per-lane registers (clipped colour indices, the end
-            // bins of the centi-bel histogram) and values that are not counted at all (surplus frames, dropped keys) send
-            // their LDS atomic to a per-lane trash word instead of serialising on one hot address.
+            // s_cbhist is indexed by level (= 999 - bin): the flush reverses it.
+            if (live) {
+            // all 32 edge reads of the frame are in flight before the first comparison needs one
+            double abs2_all[16], ge_all[16], ce_all[16];
+            int gc_all[16], lc_all[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                abs2_all[e] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
+                mn = min_nn(mn, abs2_all[e]);
+                mx = max_nn(mx, abs2_all[e]);
+                // f32 range is enough: the host only selects this kernel when every edge lies in [2^-100, 2^100], so a
+                // |X|^2 that under- or overflows f32 is clipped either way (sp_api.hip plan_lds_capable)
+                const float l2 = __log2f((float)abs2_all[e]);
+                // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
+                gc_all[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
+                lc_all[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
+                ge_all[e] = s_gedge[gc_all[e] + 1];
+                ce_all[e] = s_cbedge[lc_all[e] + 1];
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                double abs2[8], ge[8], ce[8];
-                int gc[8], lc[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int e = h * 8 + k;
-                    abs2[k] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
-                    mn = min_nn(mn, abs2[k]);
-                    mx = max_nn(mx, abs2[k]);
-                    int ex;
-                    const double mant = frexp(abs2[k], &ex);
-                    const float l2 = (float)ex + __log2f((float)mant);
-                    // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
-                    gc[k] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
-                    lc[k] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    ge[k] = s_gedge[gc[k] + 1];
-                    ce[k] = s_cbedge[lc[k] + 1];
-                }
+                const double *abs2 = abs2_all + h * 8, *ge = ge_all + h * 8, *ce = ce_all + h * 8;
+                const int *gc = gc_all + h * 8, *lc = lc_all + h * 8;
+                // colour index: clipped values (typical images are full of them) are counted per wave with s_bcnt1 on the
+                // compare masks instead of hammering one LDS word; their atomic goes to a per-lane trash word
+                int lvm1[8];                 // centi-bel level - 1
+                unsigned int lv_span = 0;    // max over the half of (level - 1) as unsigned: >= 999 iff a level is 0 or 1000
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int e = h * 8 + k;
                     const int gr = gc[k] + (abs2[k] >= ge[k] ? 1 : 0);
-                    const int lv = lc[k] + (abs2[k] >= ce[k] ? 1 : 0);
-                    // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0            worker.js:105
-                    const bool special = !(abs2[k] > 0.0) || abs2[k] == spjs::inf();
-                    trow[tl + e * T] = (unsigned char)gr;
+                    lvm1[k] = lc[k] - 1 + (abs2[k] >= ce[k] ? 1 : 0);
+                    lv_span = max(lv_span, (unsigned int)lvm1[k]);
+                    if (!(a.dbg & 512)) trow[tl + e * T] = (unsigned char)gr;
                     const bool g0 = gr == 0, gm = gr == cmax;
-                    cnt_g0 += (live && g0) ? 1u : 0u;
-                    cnt_gmax += (live && gm) ? 1u : 0u;
-                    atomicAdd((g0 || gm || !live) ? trash : &s_chist[gr], 1u);
-                    const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
-                    cnt_cb0 += (live && special) ? 1u : 0u;
-                    cnt_cb_last += (live && !special && l0) ? 1u : 0u;
-                    atomicAdd((special || l0 || lx || !live) ? trash : &s_cbhist[SP_CB_HIST_SIZE - 1 - lv], 1u);
-                    // one bin at a time: interleaving the eight bins keeps ~50 compare masks alive and spills SGPRs
+                    cnt_g0 += (unsigned int)__popcll(__ballot(g0));
+                    cnt_gmax += (unsigned int)__popcll(__ballot(gm));
+                    if (!(a.dbg & 64)) atomicAdd((g0 || gm) ? trash : &s_chist[gr], 1u);
+                    // one bin at a time: interleaving the eight bins keeps the compare masks alive and spills SGPRs
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // centi-bel histogram: levels 1..999 are plain LDS atomics; the ends (below -100 dBfs, above 0 dBfs, and the
+                // -inf / +inf / NaN keys of worker.js:105) are rare and take a wave-uniform slow path for the whole half
+                if (__builtin_expect(__ballot(lv_span >= (unsigned int)(SP_CB_HIST_SIZE - 1)) == 0ull, 1)) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (!(a.dbg & 128)) atomicAdd(&s_cbhist[1 + lvm1[k]], 1u);
+                } else {
+#pragma unroll 1
+                    for (int k = 0; k < 8; k++) {
+                        double a2 = abs2[0];
+#pragma unroll
+                        for (int j = 1; j < 8; j++) a2 = k == j ? abs2[j] : a2;
+                        int lv = lvm1[0];
+#pragma unroll
+                        for (int j = 1; j < 8; j++) lv = k == j ? lvm1[j] : lv;
+                        lv += 1;
+                        // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0        worker.js:105
+                        const bool special = !(a2 > 0.0) || a2 == spjs::inf();
+                        const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
+                        cnt_cb0 += (unsigned int)__popcll(__ballot(special));
+                        cnt_cb_last += (unsigned int)__popcll(__ballot(!special && l0));
+                        atomicAdd((special || l0 || lx) ? trash : &s_cbhist[lv], 1u);
+                    }
+                }
+            }
             }
             SP_STAMP(8);   // edge reads, compares, tile bytes, histogram atomics
-            // frame min / max over its T threads
-#pragma unroll
-            for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) {
-                mn = min_nn(mn, __shfl_xor(mn, off));
-                mx = max_nn(mx, __shfl_xor(mx, off));
-            }
-            if constexpr (WPF == 1) {
-                if (tl == 0 && live) {
-                    a.frame_min[x] = mn;
-                    a.frame_max[x] = mx;
-                }
-            } else {
-                if ((tl & 63) == 0) {
-                    s_mm[(fr * 8 + (tl >> 6)) * 2] = mn;
-                    s_mm[(fr * 8 + (tl >> 6)) * 2 + 1] = mx;
-                }
+            // frame min / max over its T threads: |X|^2 >= +0 and never NaN here, so the order of the doubles is the order
+            // of their bit patterns and two fire-and-forget LDS atomics replace a six-step cross-lane reduction
+            if (live) {
+                if (!(a.dbg & 256)) atomicMin(&s_mm[2 * fr], (unsigned long long)__double_as_longlong(mn));
+                atomicMax(&s_mm[2 * fr + 1], (unsigned long long)__double_as_longlong(mx));
             }
         }
         SP_STAMP(9);   // frame min/max reduction + stores
         __syncthreads();   // tile complete
         SP_STAMP(10);  // waiting for the other waves of the group
 
-        if constexpr (WPF > 1) {
-            if (tid < group_frames && x0 + tid < a.width) {
-                double mn = s_mm[tid * 16], mx = s_mm[tid * 16 + 1];
-                for (int w = 1; w < WPF; w++) {
-                    mn = min_nn(mn, s_mm[(tid * 8 + w) * 2]);
-                    mx = max_nn(mx, s_mm[(tid * 8 + w) * 2 + 1]);
-                }
-                a.frame_min[x0 + tid] = mn;
-                a.frame_max[x0 + tid] = mx;
+        if (tid < group_frames) {
+            if (x0 + tid < a.width) {
+                const unsigned long long bmn = s_mm[2 * tid], bmx = s_mm[2 * tid + 1];
+                a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
+                a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
+                blk_mn = bmn < blk_mn ? bmn : blk_mn;
+                blk_mx = bmx > blk_mx ? bmx : blk_mx;
             }
+            s_mm[2 * tid] = 0x7ff0000000000000ull;   // +inf, 0: ready for the next group (barrier below)
+            s_mm[2 * tid + 1] = 0ull;
         }
 
         // ---- tile -> RGBA -------------------------------------------------------------------------------------
-        if (a.rgba) {
+        if (a.rgba && !(a.dbg & 32)) {
             if (!a.waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
                 // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
@@ -693,15 +743,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     }
 #endif
     // ---- flush histograms ----------------------------------------------------------------------------------------
-    if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);          // per-lane counters of the clipped / end bins
-    if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
-    if (cnt_cb_last) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb_last);
-    if (cnt_cb0) atomicAdd(&s_cbhist[0], cnt_cb0);
+    if (tid < group_frames) {                            // extreme |X|^2 of the launch (dBfs range, k_finish_frames)
+        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], blk_mn);
+        if (blk_mx != 0ull) atomicMax(&a.mm_acc[1], blk_mx);
+    }
+    if ((tid & 63) == 0) {                               // per-wave counters of the clipped / end bins
+        if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
+        if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
+        if (cnt_cb_last) atomicAdd(&s_cbhist[0], cnt_cb_last);                 // level 0 = bin 999
+        if (cnt_cb0) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb0);       // specials = bin 0
+    }
     __syncthreads();
+    if (a.dbg & 16) return;
     for (int i = tid; i < a.lut_len; i += kLdsThreads)
         if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads)
-        if (s_cbhist[i]) atomicAdd(&a.cb_hist[i], (unsigned long long)s_cbhist[i]);
+        if (s_cbhist[i]) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)s_cbhist[i]);
 }
 
 // Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
@@ -710,7 +767,10 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut || a.lut_len < 2 || !(a.gray_b <= kLdsMaxGrayB)) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
     // tile height: 32 frames give 128-byte row segments; small images use shorter groups so every CU gets work
-    int want = 32;
+    static const int want_env = getenv("SP_GROUP_FRAMES") ? atoi(getenv("SP_GROUP_FRAMES")) : 32;   // experiments only
+    int want = want_env;
+    static const int cu_env = getenv("SP_CU_LIMIT") ? atoi(getenv("SP_CU_LIMIT")) : 0;   // experiments only
+    if (cu_env > 0 && cu_env < cu_count) cu_count = cu_env;
     while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
     const int gf = lds_group_frames(n, want);
     const int groups = (a.width + gf - 1) / gf;

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameA
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kScratchThreads) s_cb_hist[i] = 0;
     __syncthreads();
 
+    double blk_mn = spjs::inf(), blk_mx = 0.0;   // thread 0: over this workgroup's frames
     for (int x = a.frame0 + blockIdx.x; x < a.width; x += gridDim.x) {
         const int64_t start = frame_start(a.stride, x);
 
@@ -114,10 +115,16 @@ __global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameA
             }
             a.frame_min[x] = mn;
             a.frame_max[x] = mx;
+            blk_mn = min_nn(blk_mn, mn);
+            blk_mx = max_nn(blk_mx, mx);
         }
         __syncthreads();   // scratch slab and s_red are reused by the next frame
     }
 
+    if (tid == 0) {   // abs2 >= +0 and never NaN here: the order of the doubles is the order of their bit patterns
+        atomicMin(&a.mm_acc[0], (unsigned long long)__double_as_longlong(blk_mn));
+        atomicMax(&a.mm_acc[1], (unsigned long long)__double_as_longlong(blk_mx));
+    }
     for (int i = tid; i < a.lut_len; i += kScratchThreads)
         if (s_c_hist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_c_hist[i]);
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kScratchThreads)
@@ -134,9 +141,13 @@ struct FinishArgs {
     double block_norm_db, gain, range;
     const double *frame_min, *frame_max;
     uint8_t *gauge_mins, *gauge_maxs, *gauge_amps;
-    double *partial;          // [gridDim.x * 2]
-    unsigned int *ticket;     // arrival counter, zero before and after every launch
+    unsigned long long *mm_acc;   // [2] bit patterns of min / max |X|^2 over all frames; reset to {+inf, 0} here
     double *out_minmax;       // [2] or nullptr
+    // histograms: the frame-loop kernels add into context-owned accumulators (zero before and after every launch);
+    // this kernel moves them to the caller's arrays, so a reply always holds the counts of its own request
+    int32_t lut_len;
+    unsigned long long *acc_c, *acc_cb;
+    unsigned long long *out_c, *out_cb;   // or nullptr
 };
 
 // store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
@@ -161,23 +172,33 @@ __device__ inline double centre_sample(int fmt, const spfmt::View &v, int64_t po
 
 constexpr int kFinishThreads = 256;
 
+// d = dBfs - gain of one |X|^2 value, the reference's operation order                     worker.js:100,124-125
+__device__ inline double d_of_abs2(double abs2, double block_norm_db, double gain) { return (5 * spjs::log10(abs2) + block_norm_db + gain) - gain; }
+
+// Grid: 3 * ceil(width / kFinishThreads) workgroups (at least enough threads for the histograms).  The three software
+// log10 evaluations a frame needs are independent, so they run in different workgroups (role = blockIdx % 3) instead of as
+// one long dependent chain per thread.
 __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishArgs a)
 {
-    __shared__ double s_red[2 * (kFinishThreads / 64)];
-    const int x = blockIdx.x * kFinishThreads + threadIdx.x;
-    double dmin = 0.0, dmax = -200.0;   // worker.js:35-36
+    const int role = blockIdx.x % 3;
+    const int x = (blockIdx.x / 3) * kFinishThreads + threadIdx.x;
     if (x < a.width) {
-        // d = dBfs - gain is monotone in abs2, so the frame's extreme d values come from its extreme abs2 values
-        const double dlo = (5 * spjs::log10(a.frame_min[x]) + a.block_norm_db + a.gain) - a.gain;
-        const double dhi = (5 * spjs::log10(a.frame_max[x]) + a.block_norm_db + a.gain) - a.gain;
-        double fmin = 0.0, fmax = -200.0;   // worker.js:82-83
-        if (dlo < fmin) fmin = dlo;
-        if (dhi > fmax) fmax = dhi;
-        dmin = fmin;
-        dmax = fmax;
-        if (a.gauge_mins) a.gauge_mins[x] = clamp_u8(0.5 + (a.range + fmin) * 256 / a.range);
-        if (a.gauge_maxs) a.gauge_maxs[x] = clamp_u8(0.5 + (a.range + fmax) * 256 / a.range);
-        if (a.gauge_amps) {
+        // d is monotone in abs2, so the frame's extreme d values come from its extreme abs2 values
+        if (role == 0) {
+            if (a.gauge_mins) {
+                const double dlo = d_of_abs2(a.frame_min[x], a.block_norm_db, a.gain);
+                double fmin = 0.0;   // worker.js:82
+                if (dlo < fmin) fmin = dlo;
+                a.gauge_mins[x] = clamp_u8(0.5 + (a.range + fmin) * 256 / a.range);
+            }
+        } else if (role == 1) {
+            if (a.gauge_maxs) {
+                const double dhi = d_of_abs2(a.frame_max[x], a.block_norm_db, a.gain);
+                double fmax = -200.0;   // worker.js:83
+                if (dhi > fmax) fmax = dhi;
+                a.gauge_maxs[x] = clamp_u8(0.5 + (a.range + fmax) * 256 / a.range);
+            }
+        } else if (a.gauge_amps) {
             const spfmt::View v{a.bytes, a.nbytes, a.nelem};
             const int64_t mid = (int64_t)frame_start(a.stride, x) + (a.n >> 1);
             const double ci = centre_sample(a.format, v, mid, 0), cq = centre_sample(a.format, v, mid, 1);
@@ -185,60 +206,32 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
             a.gauge_amps[x] = clamp_u8(0.5 + (a.range + amp) * 256 / a.range);
         }
     }
-    // dmin <= 0 and dmax >= -200 are never NaN here
-    for (int off = 32; off > 0; off >>= 1) {
-        dmin = fmin(dmin, __shfl_xor(dmin, off));
-        dmax = fmax(dmax, __shfl_xor(dmax, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_red[2 * (threadIdx.x >> 6)] = dmin;
-        s_red[2 * (threadIdx.x >> 6) + 1] = dmax;
-    }
-    __syncthreads();
-    __shared__ bool s_last;
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kFinishThreads / 64; w++) {
-            dmin = fmin(dmin, s_red[2 * w]);
-            dmax = fmax(dmax, s_red[2 * w + 1]);
+    {
+        // histograms: accumulators -> reply, accumulators back to zero
+        const int gi = blockIdx.x * kFinishThreads + threadIdx.x;
+        if (gi < a.lut_len) {
+            const unsigned long long v = a.acc_c[gi];
+            if (a.out_c) a.out_c[gi] = v;
+            a.acc_c[gi] = 0ull;
         }
-        // publish this block's partial, then take a ticket: the block that arrives last reduces all partials
-        // (agent-scope release on the producers, acquire on the consumer; write-through stores so no L2 line stays dirty)
-        __hip_atomic_store(&a.partial[2 * blockIdx.x], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.partial[2 * blockIdx.x + 1], dmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last || !a.out_minmax) {
-        if (s_last && threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double rmin = 0.0, rmax = -200.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kFinishThreads) {
-        rmin = fmin(rmin, __hip_atomic_load(&a.partial[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        rmax = fmax(rmax, __hip_atomic_load(&a.partial[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        rmin = fmin(rmin, __shfl_xor(rmin, off));
-        rmax = fmax(rmax, __shfl_xor(rmax, off));
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        s_red[2 * (threadIdx.x >> 6)] = rmin;
-        s_red[2 * (threadIdx.x >> 6) + 1] = rmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kFinishThreads / 64; w++) {
-            rmin = fmin(rmin, s_red[2 * w]);
-            rmax = fmax(rmax, s_red[2 * w + 1]);
+        if (gi < SP_CB_HIST_SIZE) {
+            const unsigned long long v = a.acc_cb[gi];
+            if (a.out_cb) a.out_cb[gi] = v;
+            a.acc_cb[gi] = 0ull;
         }
-        a.out_minmax[0] = rmin;
-        a.out_minmax[1] = rmax;
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    // global dBfs range (worker.js:35-36,124-125): min over frames of min(0, d(frame_min)) = min(0, d(min over frames)),
+    // by the same monotonicity; the frame-loop kernels left the extreme |X|^2 of the whole launch in mm_acc
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        const double v = __longlong_as_double((long long)a.mm_acc[threadIdx.x]);
+        const double d = d_of_abs2(v, a.block_norm_db, a.gain);
+        if (threadIdx.x == 0) {
+            if (a.out_minmax) a.out_minmax[0] = d < 0.0 ? d : 0.0;
+            a.mm_acc[0] = 0x7ff0000000000000ull;
+        } else {
+            if (a.out_minmax) a.out_minmax[1] = d > -200.0 ? d : -200.0;
+            a.mm_acc[1] = 0ull;
+        }
     }
 }
 

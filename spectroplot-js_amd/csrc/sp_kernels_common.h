@@ -27,10 +27,11 @@ struct FrameArgs {
     const uint32_t *lut_rgba;    // [lut_len] packed r | g<<8 | b<<16 | 255<<24
     float gray_a, gray_b, cb_a, cb_b;
     uint8_t *rgba;               // [4*width*n] or nullptr
-    unsigned long long *c_hist;  // [lut_len]   accumulated
-    unsigned long long *cb_hist; // [1000]      accumulated
+    unsigned long long *c_hist;  // [lut_len]   accumulators (zero before every launch, k_finish_frames moves them out)
+    unsigned long long *cb_hist; // [1000]
     double *frame_min;           // [width] min over the frame of abs2 (NaN ignored), +inf if none
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
+    unsigned long long *mm_acc;  // [2] bit patterns of the min / max of abs2 over all frames ({+inf, 0} before every launch)
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
     unsigned long long *stamps;  // diagnostic builds (SP_STAMPS): 13 counters, else nullptr
 };

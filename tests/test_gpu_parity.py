@@ -82,7 +82,7 @@ def test_golden_worker_cases_sp_render(pkg, ctx, golden):
     assert not bad, bad[:30]
 
 
-@pytest.mark.parametrize("kernel", ["scratch", "lds", "wave"])
+@pytest.mark.parametrize("kernel", ["scratch", "lds"])
 def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
     """The same vectors through sp_plan_execute with each device kernel forced (device-resident operands)."""
     bad, ran = [], 0

@@ -21,7 +21,8 @@ ctx.synth_trinoise(d_in, fmt, 0, Smax, 0x5EED0001, 7321, 11, 0.5, 0.02)
 sizes = [4 * 24576 * n, 24576, 24576, 24576, 8 * 256, 8000, 16]
 ptrs = [ctx.alloc(s) for s in sizes]
 ctx.enable_timing(True)
-for W in [12, 3072, 12288, 16384, 16416, 16512, 17408, 24576]:
+Ws = [int(w) for w in os.environ["SP_WIDTHS"].split(",")] if os.environ.get("SP_WIDTHS") else [12, 3072, 12288, 16384, 16416, 16512, 17408, 24576]
+for W in Ws:
     ms = []
     for r in range(12):
         plan.execute(d_in, W * n * sw, W, *ptrs)
