@@ -553,10 +553,6 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.in_bounds = in_bounds ? 1 : 0;
     a.frame0 = 0;
     a.sample_width = f.width;
-    {
-        static const int dbg_flags = getenv("SP_DEBUG_FLAGS") ? atoi(getenv("SP_DEBUG_FLAGS")) : 0;   // profiling ablations only
-        a.dbg = dbg_flags;
-    }
     a.window = plan->d_window;
     a.cos_t = plan->d_cos;
     a.sin_t = plan->d_sin;
@@ -571,25 +567,6 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.frame_min = (double *)ctx->frame_minmax.p;
     a.frame_max = a.frame_min + width;
     a.scratch = nullptr;
-    a.stamps = nullptr;
-#ifdef SP_STAMPS
-    {
-        static unsigned long long *d_stamps = nullptr;
-        if (!d_stamps) { (void)hipMalloc(&d_stamps, 16 * 8); (void)hipMemset(d_stamps, 0, 16 * 8); }
-        a.stamps = d_stamps;
-        if (getenv("SP_STAMPS_DUMP")) {
-            unsigned long long h[16];
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost);
-            static const char *names[12] = {"loop", "load+decode", "pass0", "xchg1", "pass1", "xchg2", "pass2", "abs2+guess", "classify+hist", "minmax", "barrier wait", "writeout"};
-            unsigned long long tot = 0;
-            for (int k = 0; k < 12; k++) tot += h[k];
-            fprintf(stderr, "[stamps] waves=%llu total cycles/wave=%.0f\n", h[12], h[12] ? (double)tot / h[12] : 0.0);
-            for (int k = 0; k < 12; k++) fprintf(stderr, "[stamps] %-14s %6.2f %%\n", names[k], tot ? 100.0 * h[k] / tot : 0.0);
-            (void)hipMemset(d_stamps, 0, 16 * 8);
-        }
-    }
-#endif
 
     // the kernels count into the context's accumulators; the finish kernel moves the counts to the reply
     a.mm_acc = (unsigned long long *)((char *)ctx->partial.p + 16);

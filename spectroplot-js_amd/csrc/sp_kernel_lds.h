@@ -29,10 +29,7 @@
 
 namespace spk {
 
-#ifndef SP_LDS_THREADS
-#define SP_LDS_THREADS 512
-#endif
-constexpr int kLdsThreads = SP_LDS_THREADS;
+constexpr int kLdsThreads = 512;
 constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
 constexpr int kLdsMaxLut = 256;      // colour indices travel through a byte tile
 constexpr float kLdsMaxGrayB = 2000.0f;   // first-guess slope bound that keeps the one-compare correction exact
@@ -304,19 +301,6 @@ __device__ inline void decode_frame(const uint32_t (&lo)[16], const uint32_t (&h
     }
 }
 
-// Diagnostic build only (make STAMPS=1): per-phase s_memtime totals of wave 0 of every workgroup go to a.stamps.  The stamp's
-// own s_waitcnt drains outstanding LDS/SMEM operations, so such a build shows SHARES of a frame, never a valid run time.
-#ifdef SP_STAMPS
-#define SP_STAMP(k)                                                                             \
-    do {                                                                                        \
-        unsigned long long t_;                                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-        stamp_acc[k] += t_ - stamp_prev;                                                        \
-        stamp_prev = t_;                                                                        \
-    } while (0)
-#else
-#define SP_STAMP(k) do { } while (0)
-#endif
 
 template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
@@ -329,7 +313,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
     constexpr int NPASS = (LOG2N + 3) / 4;
 
-    if (a.dbg & 2048) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
     double *s_xch = (double *)smem;
@@ -349,6 +332,27 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     double *xbuf = s_xch + fs * (N + N / 16);
     const int tile_pitch = N + kTilePad;
     const int cmax = a.lut_len - 1;
+
+    // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
+    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int chunk = (groups + 7) >> 3;
+    const int g_end = min(groups, (xcd + 1) * chunk);
+
+    // register prefetch is used for the common sample widths when every frame lies inside the buffer
+    // (PFB is chosen by the host: frames inside the buffer and 2-, 4- or 8-byte samples)
+    constexpr bool PF = PFB != 0;
+    const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    const int rounds = group_frames / FPB;
+    uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
+    auto request = [&](int xq) {
+        if constexpr (PF) {
+        const int xc = xq < a.width ? xq : a.width - 1;
+        const int64_t st = frame_start(a.stride, xc);
+        issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi);
+        }
+    };
+    // the first frame's samples are requested before the tables: one HBM round trip for both
+    if (PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
 
     {
         // request tables -> LDS: every global load is issued before the first LDS store, so the prologue costs one memory
@@ -404,39 +408,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         s_mm[2 * tid + 1] = 0ull;
     }
     __syncthreads();
-    if (a.dbg & 1024) return;
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
-#ifdef SP_STAMPS
-    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
     // clipped colour indices and the end bins of the centi-bel histogram are counted in per-wave (scalar) registers
     // (they dominate typical images and would serialise as same-address LDS atomics)
     unsigned int cnt_g0 = 0, cnt_gmax = 0, cnt_cb_last = 0, cnt_cb0 = 0;
     const float gray_a = a.gray_a, gray_b = a.gray_b, cb_a = a.cb_a, cb_b = a.cb_b;
     const float gc_hi = (float)(cmax - 1);
-
-    // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
-    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int chunk = (groups + 7) >> 3;
-    const int g_end = min(groups, (xcd + 1) * chunk);
-
-    // register prefetch is used for the common sample widths when every frame lies inside the buffer
-    // (PFB is chosen by the host: frames inside the buffer and 2-, 4- or 8-byte samples)
-    constexpr bool PF = PFB != 0;
-    const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
-    const int rounds = group_frames / FPB;
-    uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
-    auto request = [&](int xq) {
-        if constexpr (PF) {
-        const int xc = xq < a.width ? xq : a.width - 1;
-        const int64_t st = frame_start(a.stride, xc);
-        issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi);
-        }
-    };
-    if (PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
@@ -447,7 +426,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             const bool live = xr < a.width;
             const int x = live ? xr : a.width - 1;  // surplus slots recompute the last frame and discard it
             const int64_t start = frame_start(a.stride, x);
-            SP_STAMP(0);   // loop control
 
             double re[16], im[16];
             double win[16];
@@ -495,9 +473,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
-            SP_STAMP(1);   // touch + input loads + decode + taper
             fft_pass<0, 1, 4>(re, im, tw0);
-            SP_STAMP(2);   // pass 0
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
@@ -506,9 +482,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 load_pass_tw(tw1, tl, s_tw, tw);
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
-                SP_STAMP(3);   // exchange 1 (LDS)
                 fft_pass<WS1, 5, E1>(re, im, tw1);
-                SP_STAMP(4);   // pass 1
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
@@ -522,9 +496,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
                         exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
                     }
-                    SP_STAMP(5);   // exchange 2 (permlane or LDS)
                     fft_pass<WS2, 9, E2>(re, im, tw2);
-                    SP_STAMP(6);   // pass 2
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
@@ -611,11 +583,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                     const int gr = gc[k] + (abs2[k] >= ge[k] ? 1 : 0);
                     lvm1[k] = lc[k] - 1 + (abs2[k] >= ce[k] ? 1 : 0);
                     lv_span = max(lv_span, (unsigned int)lvm1[k]);
-                    if (!(a.dbg & 512)) trow[tl + e * T] = (unsigned char)gr;
+                    trow[tl + e * T] = (unsigned char)gr;
                     const bool g0 = gr == 0, gm = gr == cmax;
                     cnt_g0 += (unsigned int)__popcll(__ballot(g0));
                     cnt_gmax += (unsigned int)__popcll(__ballot(gm));
-                    if (!(a.dbg & 64)) atomicAdd((g0 || gm) ? trash : &s_chist[gr], 1u);
+                    atomicAdd((g0 || gm) ? trash : &s_chist[gr], 1u);
                     // one bin at a time: interleaving the eight bins keeps the compare masks alive and spills SGPRs
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -623,7 +595,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 // -inf / +inf / NaN keys of worker.js:105) are rare and take a wave-uniform slow path for the whole half
                 if (__builtin_expect(__ballot(lv_span >= (unsigned int)(SP_CB_HIST_SIZE - 1)) == 0ull, 1)) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) if (!(a.dbg & 128)) atomicAdd(&s_cbhist[1 + lvm1[k]], 1u);
+                    for (int k = 0; k < 8; k++) atomicAdd(&s_cbhist[1 + lvm1[k]], 1u);
                 } else {
 #pragma unroll 1
                     for (int k = 0; k < 8; k++) {
@@ -644,17 +616,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 }
             }
             }
-            SP_STAMP(8);   // edge reads, compares, tile bytes, histogram atomics
             // frame min / max over its T threads: |X|^2 >= +0 and never NaN here, so the order of the doubles is the order
             // of their bit patterns and two fire-and-forget LDS atomics replace a six-step cross-lane reduction
             if (live) {
-                if (!(a.dbg & 256)) atomicMin(&s_mm[2 * fr], (unsigned long long)__double_as_longlong(mn));
+                atomicMin(&s_mm[2 * fr], (unsigned long long)__double_as_longlong(mn));
                 atomicMax(&s_mm[2 * fr + 1], (unsigned long long)__double_as_longlong(mx));
             }
         }
-        SP_STAMP(9);   // frame min/max reduction + stores
         __syncthreads();   // tile complete
-        SP_STAMP(10);  // waiting for the other waves of the group
 
         if (tid < group_frames) {
             if (x0 + tid < a.width) {
@@ -669,7 +638,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         }
 
         // ---- tile -> RGBA -------------------------------------------------------------------------------------
-        if (a.rgba && !(a.dbg & 32)) {
+        if (a.rgba) {
             if (!a.waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
                 // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
@@ -733,15 +702,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
         }
         __syncthreads();   // tile and s_mm are reused by the next group
-        SP_STAMP(11);  // tile -> RGBA write-out + barrier
     }
 
-#ifdef SP_STAMPS
-    if (a.stamps && (tid & 63) == 0) {
-        for (int k = 0; k < 12; k++) atomicAdd(&a.stamps[k], stamp_acc[k]);
-        atomicAdd(&a.stamps[12], 1ull);
-    }
-#endif
     // ---- flush histograms ----------------------------------------------------------------------------------------
     if (tid < group_frames) {                            // extreme |X|^2 of the launch (dBfs range, k_finish_frames)
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], blk_mn);
@@ -754,7 +716,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         if (cnt_cb0) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb0);       // specials = bin 0
     }
     __syncthreads();
-    if (a.dbg & 16) return;
     for (int i = tid; i < a.lut_len; i += kLdsThreads)
         if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads)
@@ -767,9 +728,8 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut || a.lut_len < 2 || !(a.gray_b <= kLdsMaxGrayB)) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
     // tile height: 32 frames give 128-byte row segments; small images use shorter groups so every CU gets work
-    static const int want_env = getenv("SP_GROUP_FRAMES") ? atoi(getenv("SP_GROUP_FRAMES")) : 32;   // experiments only
-    int want = want_env;
-    static const int cu_env = getenv("SP_CU_LIMIT") ? atoi(getenv("SP_CU_LIMIT")) : 0;   // experiments only
+    int want = 32;
+    static const int cu_env = getenv("SP_CU_LIMIT") ? atoi(getenv("SP_CU_LIMIT")) : 0;   // measurements only (tools/overhead.py)
     if (cu_env > 0 && cu_env < cu_count) cu_count = cu_env;
     while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
     const int gf = lds_group_frames(n, want);

@@ -18,7 +18,6 @@ struct FrameArgs {
     int32_t in_bounds;           // every frame lies inside the buffer: unchecked loads are safe
     int32_t frame0;              // first frame of this launch (always 0 today)
     int32_t sample_width;        // bytes per complex sample
-    int32_t dbg;                 // ablation switches for profiling builds (SP_DEBUG_FLAGS); 0 in production
     const double *window;        // [n]
     const double *cos_t;         // [n/2]
     const double *sin_t;         // [n/2]
@@ -33,7 +32,6 @@ struct FrameArgs {
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
     unsigned long long *mm_acc;  // [2] bit patterns of the min / max of abs2 over all frames ({+inf, 0} before every launch)
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
-    unsigned long long *stamps;  // diagnostic builds (SP_STAMPS): 13 counters, else nullptr
 };
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
