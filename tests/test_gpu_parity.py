@@ -308,3 +308,91 @@ def test_baseline_config_shapes_sampled_frames(pkg, ctx, golden, cfg):
     for p in ptrs + [d_in]:
         ctx.free(p)
     plan.close()
+
+
+def _assert_same(got, want):
+    for k in ("rgba", "gauge_mins", "gauge_maxs", "gauge_amps"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["c_hist"].astype(np.int64), want["c_hist"])
+    assert np.array_equal(got["cB_hist"].astype(np.int64), want["cB_hist"])
+    for k in ("dBfs_min", "dBfs_max"):
+        a, b = np.float64(got[k]), np.float64(want[k])
+        assert (a != a and b != b) or a.view(np.uint64) == b.view(np.uint64), k
+
+
+@pytest.mark.parametrize("gain,rng,bn_scale", [(6.0, 30.0, 1.0), (2500.0, 30.0, 1.0), (-2500.0, 30.0, 1.0), (6.0, 3000.0, 1.0),
+                                               (6.0, 30.0, 1e-140), (6.0, 30.0, 1e140), (40.0, 0.75, 1.0)],
+                         ids=["plain", "gain+2500", "gain-2500", "range3000", "norm1e-140", "norm1e140", "range0.75"])
+def test_extreme_gain_range_norm(pkg, ctx, gain, rng, bn_scale):
+    """Requests whose colour / centi-bel edges leave the f32 range (the LDS kernel's first guess) or whose colour steps are
+    finer than its guess tolerates must still be bit-exact (they run on the scratch kernel)."""
+    n, W, fmt = 1024, 96, "CF32"
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 99, "step": 4099, "gshift": 9, "amp": 0.5, "namp": 0.02}, n * W)
+    win, weight = pyoracle.window("hann", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    bn = bn_scale / weight
+    want = pyoracle.render(fmt, data, n, win, bn, gain, rng, lut, W)
+    got = ctx.render(fmt, data, n, win, bn, gain, rng, lut, W)
+    _assert_same(got, want)
+
+
+@pytest.mark.parametrize("fmt", ["CF32", "CF64", "CS16"])
+def test_silence_and_nonfinite_samples(pkg, ctx, fmt):
+    """Frames of exact zeros (|X|^2 = 0: -inf dB, centi-bel key 0), frames with infinities and NaNs (float formats) and ordinary
+    frames in one capture: the rare-path branches of the histogram code against the oracle."""
+    n, W = 1024, 64
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 5, "step": 4099, "gshift": 9, "amp": 0.5, "namp": 0.02}, n * W)
+    sw = data.size // (n * W)
+    data = data.copy()
+    data[8 * n * sw:24 * n * sw] = 0                                  # 16 silent frames
+    if fmt.startswith("CF"):
+        v = data.view(np.float32 if fmt == "CF32" else np.float64)
+        per = 2 * n
+        v[30 * per + 17] = np.inf
+        v[31 * per + 400] = -np.inf
+        v[33 * per + 1] = np.nan
+        v[40 * per:41 * per] = 1e30 if fmt == "CF32" else 1e200      # overflow of |X|^2 in f32 / towards inf
+        v[41 * per:42 * per] = 1e-30 if fmt == "CF32" else 1e-200    # underflow of the f32 first guess
+    win, weight = pyoracle.window("blackmanHarris", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    for ch in (False, True):
+        want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W, ch)
+        got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W, ch)
+        _assert_same(got, want)
+
+
+def test_reply_is_overwritten_not_accumulated(pkg, ctx):
+    """Two executions of one plan into the same reply buffers leave the counts of ONE request (include/spectroplot_hip.h),
+    for both kernels, and a zero-width request clears them."""
+    n, W, fmt = 1024, 40, "CU8"
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 3, "step": 4099, "gshift": 9, "amp": 0.5, "namp": 0.02}, n * W)
+    win, weight = pyoracle.window("hann", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W)
+    for kernel in ("lds", "scratch"):
+        plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+        plan.force_kernel(kernel)
+        d_in = ctx.alloc(data.size)
+        ctx.upload(d_in, data)
+        sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+        ptrs = [ctx.alloc(s) for s in sizes]
+        for p, s in zip(ptrs, sizes):
+            ctx.memset(p, 0xA5, s)                                     # stale contents must not survive
+        for _ in range(3):
+            plan.execute(d_in, data.size, W, *ptrs)
+        ctx.synchronize()
+        assert np.array_equal(ctx.download(ptrs[4], 8 * 256, np.uint64).astype(np.int64), want["c_hist"]), kernel
+        assert np.array_equal(ctx.download(ptrs[5], 8000, np.uint64).astype(np.int64), want["cB_hist"]), kernel
+        mm = ctx.download(ptrs[6], 16, np.float64)
+        assert mm[0] == want["dBfs_min"] and mm[1] == want["dBfs_max"], kernel
+        plan.execute(d_in, data.size, 0, *ptrs)
+        ctx.synchronize()
+        assert not ctx.download(ptrs[4], 8 * 256, np.uint64).any() and not ctx.download(ptrs[5], 8000, np.uint64).any(), kernel
+        mm = ctx.download(ptrs[6], 16, np.float64)
+        assert mm[0] == 0.0 and mm[1] == -200.0, kernel
+        for p in ptrs + [d_in]:
+            ctx.free(p)
+        plan.close()
