@@ -33,6 +33,10 @@ constexpr int kLdsThreads = 512;
 constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
 constexpr int kLdsMaxLut = 256;      // colour indices travel through a byte tile
 constexpr float kLdsMaxGrayB = 2000.0f;   // first-guess slope bound that keeps the one-compare correction exact
+#ifndef SP_HIST_COPIES
+#define SP_HIST_COPIES 1
+#endif
+constexpr int kHistCopies = SP_HIST_COPIES;   // LDS histogram copies (lanes are dealt over them): fewer same-word atomics
 constexpr int kTilePad = 4;   // tile row pitch = n + 4 bytes: conflict-free dword reads across 8 frame quads
 
 __host__ __device__ inline bool lds_kernel_supports(int n)
@@ -62,6 +66,10 @@ __host__ __device__ inline constexpr int lds_tw_entries(int n)
 
 __host__ __device__ inline constexpr bool lds_win_in_lds(int n) { return n <= 1024; }
 
+// The T threads of a frame fold their extreme |X|^2 into LDS with atomics; lanes are spread over this many slots per frame so
+// that at most 4 lanes of a wave meet on one word (64 on one word cost ~5 % of the kernel).
+__host__ __device__ inline constexpr int lds_mm_slots(int n) { return n / 64 < 1 ? 1 : (n / 64 > 16 ? 16 : n / 64); }
+
 struct LdsLayout {
     int xch_doubles;   // exchange buffer (all frames of a round)
     int tile_bytes;
@@ -78,11 +86,12 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int lut_len, int group_fr
     l.off_tw = o;     o += lds_tw_entries(n) * 16;     // per-stage twiddles of stages 5..10 (16-byte aligned)
     l.off_gedge = o;  o += lut_len * 8;
     l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
-    l.off_mm = o;     o += group_frames * 2 * 8;       // per frame {min, max} of |X|^2 as bit patterns (LDS atomics)
+    o = (o + 15) & ~15;
+    l.off_mm = o;     o += group_frames * lds_mm_slots(n) * 2 * 8;   // per frame and lane slot {min, max} of |X|^2 (bit patterns)
     l.off_tile = o;   o += (l.tile_bytes + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
-    l.off_chist = o;  o += lut_len * 4;
-    l.off_cbhist = o; o += SP_CB_HIST_SIZE * 4;
+    l.off_chist = o;  o += lut_len * 4 * kHistCopies;
+    l.off_cbhist = o; o += SP_CB_HIST_SIZE * 4 * kHistCopies;
     l.off_trash = o;  o += kLdsThreads * 4;
     o = (o + 7) & ~7;
     l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;   // taper (n <= 1024: frees 32 VGPRs for the input prefetch)
@@ -111,7 +120,7 @@ __device__ inline constexpr int win_off(int e, int ws) { return (e << ws) + ((e 
 template <int WS, int S0, int S1>
 struct PassTw {
     static constexpr int count = (1 << (S1 - WS)) - (1 << (S0 - 1 - WS));
-    double2 w[count];
+    double2 w[count > 0 ? count : 1];
 };
 
 // tw_lds: LDS copy of stage_tw[0 .. min(n, 1024)), tw_glb: the full table in HBM/L2.  Issued as one batch well before the
@@ -302,6 +311,27 @@ __device__ inline void decode_frame(const uint32_t (&lo)[16], const uint32_t (&h
 }
 
 
+// A register pass whose twiddles are read stage by stage instead of as one batch ahead of the re-distribution.
+template <int WS, int S0, int S1>
+__device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ tw_lds,
+                                       const double2 *__restrict__ tw_glb)
+{
+    if constexpr (S0 <= S1) {
+        PassTw<WS, S0, S0> t;
+        load_pass_tw(t, tl, tw_lds, tw_glb);
+        fft_pass<WS, S0, S0>(re, im, t);
+        asm volatile("" ::: "memory");   // keep the next stage's reads behind this stage: at most 8 twiddles are live
+        fft_pass_staged<WS, S0 + 1, S1>(re, im, tl, tw_lds, tw_glb);
+    }
+}
+
+#ifndef SP_STAGED_TW
+#define SP_STAGED_TW 0
+#endif
+#ifndef SP_EPI_CHUNK
+#define SP_EPI_CHUNK 8
+#endif
+
 template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                          const int group_frames, const int groups)
@@ -312,6 +342,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     constexpr bool BLOCK_SYNC = T > 64;
     constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
     constexpr int NPASS = (LOG2N + 3) / 4;
+    constexpr bool STAGED = SP_STAGED_TW != 0 && LOG2N > 0;   // experiment switch (tools/build_variant.sh)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
@@ -324,6 +355,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
     unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);
     unsigned int *s_cbhist = (unsigned int *)(smem + lay.off_cbhist);
+    unsigned int *const my_chist = s_chist + (threadIdx.x & (kHistCopies - 1)) * a.lut_len;
+    unsigned int *const my_cbhist = s_cbhist + (threadIdx.x & (kHistCopies - 1)) * SP_CB_HIST_SIZE;
     unsigned int *const trash = (unsigned int *)(smem + lay.off_trash) + threadIdx.x;
 
     const int tid = threadIdx.x;
@@ -381,13 +414,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         if (tid < a.lut_len) {
             s_gedge[tid] = ge_r;
             s_lut[tid] = lut_r;
-            s_chist[tid] = 0;
+            for (int c = 0; c < kHistCopies; c++) s_chist[tid + c * a.lut_len] = 0;
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = tid + k * kLdsThreads;
             if (i <= SP_CB_HIST_SIZE) s_cbedge[i] = cb_r[k];
-            if (i < SP_CB_HIST_SIZE) s_cbhist[i] = 0;
+            if (i < SP_CB_HIST_SIZE)
+                for (int c = 0; c < kHistCopies; c++) s_cbhist[i + c * SP_CB_HIST_SIZE] = 0;
         }
     }
 
@@ -403,9 +437,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #pragma unroll
         for (int e = 0; e < 16; e++) win_reg[e] = a.window[rev4(e) * T + sidx];
     }
-    if (tid < group_frames) {
-        s_mm[2 * tid] = 0x7ff0000000000000ull;
-        s_mm[2 * tid + 1] = 0ull;
+    constexpr int MMS = lds_mm_slots(N);
+    for (int i = tid; i < group_frames * MMS; i += kLdsThreads) {
+        s_mm[2 * i] = 0x7ff0000000000000ull;
+        s_mm[2 * i + 1] = 0ull;
     }
     __syncthreads();
 
@@ -431,8 +466,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             double win[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
-            PassTw<0, 1, 4> tw0;
-            load_pass_tw(tw0, tl, s_tw, stage_tw);   // lane-uniform (broadcast reads), in flight during the decode
+            PassTw<0, 1, STAGED ? 0 : 4> tw0;
+            if constexpr (!STAGED) load_pass_tw(tw0, tl, s_tw, stage_tw);   // lane-uniform (broadcast reads), in flight during the decode
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
@@ -473,22 +508,24 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
-            fft_pass<0, 1, 4>(re, im, tw0);
+            if constexpr (STAGED) fft_pass_staged<0, 1, 4>(re, im, tl, s_tw, stage_tw);
+            else fft_pass<0, 1, 4>(re, im, tw0);
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
-                PassTw<WS1, 5, E1> tw1;
-                load_pass_tw(tw1, tl, s_tw, tw);
+                PassTw<WS1, 5, STAGED ? 4 : E1> tw1;
+                if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
-                fft_pass<WS1, 5, E1>(re, im, tw1);
+                if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
+                else fft_pass<WS1, 5, E1>(re, im, tw1);
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
-                    PassTw<WS2, 9, E2> tw2;
-                    load_pass_tw(tw2, tl, s_tw, tw);
+                    PassTw<WS2, 9, STAGED ? 8 : E2> tw2;
+                    if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
                     if constexpr (LOG2N == 9 || LOG2N == 10) {
                         exchange_permlane<LOG2N>(re);      // no LDS: v_permlane16_swap / v_permlane32_swap
                         exchange_permlane<LOG2N>(im);
@@ -496,7 +533,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
                         exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
                     }
-                    fft_pass<WS2, 9, E2>(re, im, tw2);
+                    if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
+                    else fft_pass<WS2, 9, E2>(re, im, tw2);
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
@@ -552,34 +590,39 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // Two halves of 8 bins keep the epilogue's temporaries (|X|^2, guesses, edges) at 64 VGPRs instead of 128.
             // s_cbhist is indexed by level (= 999 - bin): the flush reverses it.
             if (live) {
-            // all 32 edge reads of the frame are in flight before the first comparison needs one
-            double abs2_all[16], ge_all[16], ce_all[16];
-            int gc_all[16], lc_all[16];
+            // all edge reads of a chunk (the whole frame by default) are in flight before the first comparison needs one
+            constexpr int EC = SP_EPI_CHUNK;
+            constexpr int SC = EC < 8 ? EC : 8;   // bins per classification batch (one rare-path test each)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                abs2_all[e] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
-                mn = min_nn(mn, abs2_all[e]);
-                mx = max_nn(mx, abs2_all[e]);
+            for (int c = 0; c < 16 / EC; c++) {
+            double abs2_all[EC], ge_all[EC], ce_all[EC];
+            int gc_all[EC], lc_all[EC];
+#pragma unroll
+            for (int ee = 0; ee < EC; ee++) {
+                const int e = c * EC + ee;
+                abs2_all[ee] = re[e] * re[e] + im[e] * im[e];                      // worker.js:92
+                mn = min_nn(mn, abs2_all[ee]);
+                mx = max_nn(mx, abs2_all[ee]);
                 // f32 range is enough: the host only selects this kernel when every edge lies in [2^-100, 2^100], so a
                 // |X|^2 that under- or overflows f32 is clipped either way (sp_api.hip plan_lds_capable)
-                const float l2 = __log2f((float)abs2_all[e]);
+                const float l2 = __log2f((float)abs2_all[ee]);
                 // v_med3_f32 clamps and turns a NaN guess into 0 (NaN abs2 must end at index 0: every comparison is false)
-                gc_all[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
-                lc_all[e] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
-                ge_all[e] = s_gedge[gc_all[e] + 1];
-                ce_all[e] = s_cbedge[lc_all[e] + 1];
+                gc_all[ee] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(gray_b, l2, gray_a), 0.0f, gc_hi));
+                lc_all[ee] = floor_to_int(__builtin_amdgcn_fmed3f(fmaf(cb_b, l2, cb_a), 0.0f, (float)(SP_CB_HIST_SIZE - 1)));
+                ge_all[ee] = s_gedge[gc_all[ee] + 1];
+                ce_all[ee] = s_cbedge[lc_all[ee] + 1];
             }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const double *abs2 = abs2_all + h * 8, *ge = ge_all + h * 8, *ce = ce_all + h * 8;
-                const int *gc = gc_all + h * 8, *lc = lc_all + h * 8;
+            for (int h = 0; h < EC / SC; h++) {
+                const double *abs2 = abs2_all + h * SC, *ge = ge_all + h * SC, *ce = ce_all + h * SC;
+                const int *gc = gc_all + h * SC, *lc = lc_all + h * SC;
                 // colour index: clipped values (typical images are full of them) are counted per wave with s_bcnt1 on the
                 // compare masks instead of hammering one LDS word; their atomic goes to a per-lane trash word
-                int lvm1[8];                 // centi-bel level - 1
+                int lvm1[SC];                // centi-bel level - 1
                 unsigned int lv_span = 0;    // max over the half of (level - 1) as unsigned: >= 999 iff a level is 0 or 1000
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int e = h * 8 + k;
+                for (int k = 0; k < SC; k++) {
+                    const int e = c * EC + h * SC + k;
                     const int gr = gc[k] + (abs2[k] >= ge[k] ? 1 : 0);
                     lvm1[k] = lc[k] - 1 + (abs2[k] >= ce[k] ? 1 : 0);
                     lv_span = max(lv_span, (unsigned int)lvm1[k]);
@@ -587,7 +630,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                     const bool g0 = gr == 0, gm = gr == cmax;
                     cnt_g0 += (unsigned int)__popcll(__ballot(g0));
                     cnt_gmax += (unsigned int)__popcll(__ballot(gm));
-                    atomicAdd((g0 || gm) ? trash : &s_chist[gr], 1u);
+                    atomicAdd((g0 || gm) ? trash : &my_chist[gr], 1u);
                     // one bin at a time: interleaving the eight bins keeps the compare masks alive and spills SGPRs
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -595,46 +638,55 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 // -inf / +inf / NaN keys of worker.js:105) are rare and take a wave-uniform slow path for the whole half
                 if (__builtin_expect(__ballot(lv_span >= (unsigned int)(SP_CB_HIST_SIZE - 1)) == 0ull, 1)) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) atomicAdd(&s_cbhist[1 + lvm1[k]], 1u);
+                    for (int k = 0; k < SC; k++) atomicAdd(&my_cbhist[1 + lvm1[k]], 1u);
                 } else {
 #pragma unroll 1
-                    for (int k = 0; k < 8; k++) {
+                    for (int k = 0; k < SC; k++) {
                         double a2 = abs2[0];
 #pragma unroll
-                        for (int j = 1; j < 8; j++) a2 = k == j ? abs2[j] : a2;
+                        for (int j = 1; j < SC; j++) a2 = k == j ? abs2[j] : a2;
                         int lv = lvm1[0];
 #pragma unroll
-                        for (int j = 1; j < 8; j++) lv = k == j ? lvm1[j] : lv;
+                        for (int j = 1; j < SC; j++) lv = k == j ? lvm1[j] : lv;
                         lv += 1;
                         // -inf / +inf / NaN dB: ToInt32 gives 0, i.e. bin 0        worker.js:105
                         const bool special = !(a2 > 0.0) || a2 == spjs::inf();
                         const bool l0 = lv == 0, lx = lv == SP_CB_HIST_SIZE;
                         cnt_cb0 += (unsigned int)__popcll(__ballot(special));
                         cnt_cb_last += (unsigned int)__popcll(__ballot(!special && l0));
-                        atomicAdd((special || l0 || lx) ? trash : &s_cbhist[lv], 1u);
+                        atomicAdd((special || l0 || lx) ? trash : &my_cbhist[lv], 1u);
                     }
                 }
+            }
             }
             }
             // frame min / max over its T threads: |X|^2 >= +0 and never NaN here, so the order of the doubles is the order
             // of their bit patterns and two fire-and-forget LDS atomics replace a six-step cross-lane reduction
             if (live) {
-                atomicMin(&s_mm[2 * fr], (unsigned long long)__double_as_longlong(mn));
-                atomicMax(&s_mm[2 * fr + 1], (unsigned long long)__double_as_longlong(mx));
+                unsigned long long *slot = s_mm + 2 * (fr * MMS + (tl & (MMS - 1)));
+                atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
+                atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
         }
         __syncthreads();   // tile complete
 
         if (tid < group_frames) {
             if (x0 + tid < a.width) {
-                const unsigned long long bmn = s_mm[2 * tid], bmx = s_mm[2 * tid + 1];
+                unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
+#pragma unroll
+                for (int k = 0; k < MMS; k++) {
+                    const ulonglong2 v = *(const ulonglong2 *)(s_mm + 2 * (tid * MMS + k));
+                    bmn = v.x < bmn ? v.x : bmn;
+                    bmx = v.y > bmx ? v.y : bmx;
+                }
                 a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
                 a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
                 blk_mn = bmn < blk_mn ? bmn : blk_mn;
                 blk_mx = bmx > blk_mx ? bmx : blk_mx;
             }
-            s_mm[2 * tid] = 0x7ff0000000000000ull;   // +inf, 0: ready for the next group (barrier below)
-            s_mm[2 * tid + 1] = 0ull;
+#pragma unroll
+            for (int k = 0; k < MMS; k++)   // +inf, 0: ready for the next group (barrier below)
+                *(ulonglong2 *)(s_mm + 2 * (tid * MMS + k)) = make_ulonglong2(0x7ff0000000000000ull, 0ull);
         }
 
         // ---- tile -> RGBA -------------------------------------------------------------------------------------
@@ -705,9 +757,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     }
 
     // ---- flush histograms ----------------------------------------------------------------------------------------
-    if (tid < group_frames) {                            // extreme |X|^2 of the launch (dBfs range, k_finish_frames)
-        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], blk_mn);
-        if (blk_mx != 0ull) atomicMax(&a.mm_acc[1], blk_mx);
+    if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
+        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
+        if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
     }
     if ((tid & 63) == 0) {                               // per-wave counters of the clipped / end bins
         if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
@@ -716,10 +768,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         if (cnt_cb0) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb0);       // specials = bin 0
     }
     __syncthreads();
+    if (tid == 0) {                                      // one pair of device atomics per workgroup (dBfs range, k_finish_frames)
+        if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
+        if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
+    }
     for (int i = tid; i < a.lut_len; i += kLdsThreads)
-        if (s_chist[i]) atomicAdd(&a.c_hist[i], (unsigned long long)s_chist[i]);
+    {
+        unsigned int v = 0;
+        for (int c = 0; c < kHistCopies; c++) v += s_chist[i + c * a.lut_len];
+        if (v) atomicAdd(&a.c_hist[i], (unsigned long long)v);
+    }
     for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads)
-        if (s_cbhist[i]) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)s_cbhist[i]);
+    {
+        unsigned int v = 0;
+        for (int c = 0; c < kHistCopies; c++) v += s_cbhist[i + c * SP_CB_HIST_SIZE];
+        if (v) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)v);
+    }
 }
 
 // Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
