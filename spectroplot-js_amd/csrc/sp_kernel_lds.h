@@ -342,7 +342,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     constexpr bool BLOCK_SYNC = T > 64;
     constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
     constexpr int NPASS = (LOG2N + 3) / 4;
-    constexpr bool STAGED = SP_STAGED_TW != 0 && LOG2N > 0;   // experiment switch (tools/build_variant.sh)
+    // Twiddles of a pass are read as one batch ahead of its re-distribution, except in the generic-loader variants, whose
+    // format switch and bounds-checked loads leave no registers for the batch (SP_STAGED_TW: experiment switch).
+    constexpr bool STAGED = (SP_STAGED_TW != 0 && LOG2N > 0) || PFB == 0;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout lay = lds_layout(N, a.lut_len, group_frames);
