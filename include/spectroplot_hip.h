@@ -160,6 +160,12 @@ int sp_synth_trinoise(sp_context *ctx, void *d_bytes, int32_t format, uint64_t t
 int sp_context_last_kernel_ms(sp_context *ctx, float *ms);
 /* Enables (1) / disables (0) per-execute HIP event timing; off by default. */
 int sp_context_enable_timing(sp_context *ctx, int32_t on);
+/*
+ * Calibration for the figure above: elapsed milliseconds of the same event pair around a one-wavefront no-op kernel on the
+ * context's stream (minimum of several tries).  It is the dispatch latency an event pair adds to whatever it brackets; a
+ * profiler's kernel duration (rocprofv3 --kernel-trace) does not contain it.
+ */
+int sp_context_event_pair_overhead_ms(sp_context *ctx, float *ms);
 
 #ifdef __cplusplus
 }

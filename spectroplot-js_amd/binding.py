@@ -95,6 +95,7 @@ class Library:
         L.sp_synth_trinoise.argtypes = [vp, vp, i32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dbl, dbl]
         L.sp_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_context_enable_timing.argtypes = [vp, i32]
+        L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
 
     @classmethod
     def get(cls):
@@ -184,6 +185,11 @@ class Context:
 
     def enable_timing(self, on=True):
         self._chk(self.lib.L.sp_context_enable_timing(self.h, int(on)))
+
+    def event_pair_overhead_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.L.sp_context_event_pair_overhead_ms(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def last_kernel_ms(self):
         ms = C.c_float()

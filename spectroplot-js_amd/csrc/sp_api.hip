@@ -277,6 +277,27 @@ extern "C" int sp_context_last_kernel_ms(sp_context *ctx, float *ms)
     return SP_OK;
 }
 
+__global__ void k_noop() {}
+
+extern "C" int sp_context_event_pair_overhead_ms(sp_context *ctx, float *ms)
+{
+    if (!ctx || !ms) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    float best = 1e30f;
+    for (int i = 0; i < 8; i++) {
+        SP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, ctx->stream);
+        SP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        SP_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float t = 0;
+        SP_HIP(ctx, hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+        if (t < best) best = t;
+    }
+    ctx->timed = false;
+    *ms = best;
+    return SP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- device memory
 
 extern "C" int sp_device_alloc(sp_context *ctx, size_t nbytes, void **d_ptr)
