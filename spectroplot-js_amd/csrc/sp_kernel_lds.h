@@ -328,6 +328,9 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
 #ifndef SP_STAGED_TW
 #define SP_STAGED_TW 0
 #endif
+#ifndef SP_LATE_DRAIN
+#define SP_LATE_DRAIN 1
+#endif
 #ifndef SP_EPI_CHUNK
 #define SP_EPI_CHUNK 8
 #endif
@@ -455,6 +458,93 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     const float gc_hi = (float)(cmax - 1);
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
+    // ---- a finished group: per-frame extremes to HBM, tile -> RGBA (between two workgroup barriers) ---------------------------
+    auto drain = [&](const int x0) {
+        if (tid < group_frames) {
+            if (x0 + tid < a.width) {
+                unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
+#pragma unroll
+                for (int k = 0; k < MMS; k++) {
+                    const ulonglong2 v = *(const ulonglong2 *)(s_mm + 2 * (tid * MMS + k));
+                    bmn = v.x < bmn ? v.x : bmn;
+                    bmx = v.y > bmx ? v.y : bmx;
+                }
+                a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
+                a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
+                blk_mn = bmn < blk_mn ? bmn : blk_mn;
+                blk_mx = bmx > blk_mx ? bmx : blk_mx;
+            }
+#pragma unroll
+            for (int k = 0; k < MMS; k++)   // +inf, 0: ready for the next group (barrier below)
+                *(ulonglong2 *)(s_mm + 2 * (tid * MMS + k)) = make_ulonglong2(0x7ff0000000000000ull, 0ull);
+        }
+
+        // ---- tile -> RGBA -------------------------------------------------------------------------------------
+        if (a.rgba) {
+            if (!a.waterfall) {
+                // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
+                // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
+                const int quads = group_frames / 4;                 // frame quads per row
+                const int items = (N / 4) * quads;
+                // two items per thread and iteration: all tile reads first, then the LUT reads, then the stores, so the
+                // LDS latencies of the write-out overlap instead of adding up
+                for (int it0 = tid; it0 < items; it0 += 2 * kLdsThreads) {
+                    uint32_t gb[2][4];
+                    int i0v[2], xav[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int it = it0 + u * kLdsThreads;
+                        const int itc = it < items ? it : it0;
+                        const int fq = itc % quads, bq = itc / quads;
+                        i0v[u] = bq * 4;
+                        xav[u] = it < items ? x0 + fq * 4 : a.width;      // past the image: nothing is stored
+#pragma unroll
+                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
+                    }
+                    uint32_t px[2][4][4];
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int xa = xav[u];
+                        if (xa >= a.width) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int i = i0v[u] + j;
+                            const int y = (N / 2 - i) & (N - 1);
+                            uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                                *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
+                            }
+                        }
+                    }
+                }
+            } else {
+                // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
+                const int items = group_frames * (N / 4);
+                for (int it = tid; it < items; it += kLdsThreads) {
+                    const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
+                    const int xa = x0 + f;
+                    if (xa >= a.width) continue;
+                    const unsigned char *row = s_tile + f * tile_pitch;
+                    uint32_t px[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) px[k] = s_lut[row[(c4 + k + N / 2 + 1) & (N - 1)]];
+                    uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
+                    *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
+                }
+            }
+        }
+    };
+    int drain_x0 = -1;   // SP_LATE_DRAIN: group whose tile is still waiting for its write-out
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = g * group_frames;
         for (int r = 0; r < rounds; r++) {
@@ -583,6 +673,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 }
             }
 
+#if SP_LATE_DRAIN
+            if (drain_x0 >= 0) {   // the previous group's tile: all waves have finished it once they reach this point
+                __syncthreads();
+                drain(drain_x0);
+                __syncthreads();
+                drain_x0 = -1;
+            }
+#endif
             // ---- |X|^2 -> indices ---------------------------------------------------------------------------
             // The first guess floor(a + b*log2(abs2)) is biased half a step low, so the exact index is the guess or
             // the guess + 1; one comparison against the exact edge decides (edges: sp_host.h Thresholds).
@@ -670,94 +768,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
         }
+#if SP_LATE_DRAIN
+        drain_x0 = x0;   // drained ahead of the next epilogue (or after the loop): early waves start their next frame first
+#else
         __syncthreads();   // tile complete
-
-        if (tid < group_frames) {
-            if (x0 + tid < a.width) {
-                unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
-#pragma unroll
-                for (int k = 0; k < MMS; k++) {
-                    const ulonglong2 v = *(const ulonglong2 *)(s_mm + 2 * (tid * MMS + k));
-                    bmn = v.x < bmn ? v.x : bmn;
-                    bmx = v.y > bmx ? v.y : bmx;
-                }
-                a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
-                a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
-                blk_mn = bmn < blk_mn ? bmn : blk_mn;
-                blk_mx = bmx > blk_mx ? bmx : blk_mx;
-            }
-#pragma unroll
-            for (int k = 0; k < MMS; k++)   // +inf, 0: ready for the next group (barrier below)
-                *(ulonglong2 *)(s_mm + 2 * (tid * MMS + k)) = make_ulonglong2(0x7ff0000000000000ull, 0ull);
-        }
-
-        // ---- tile -> RGBA -------------------------------------------------------------------------------------
-        if (a.rgba) {
-            if (!a.waterfall) {
-                // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
-                // a thread owns 4 consecutive bins x 4 consecutive frames; 8 threads cover 32 frames = one 128-byte run
-                const int quads = group_frames / 4;                 // frame quads per row
-                const int items = (N / 4) * quads;
-                // two items per thread and iteration: all tile reads first, then the LUT reads, then the stores, so the
-                // LDS latencies of the write-out overlap instead of adding up
-                for (int it0 = tid; it0 < items; it0 += 2 * kLdsThreads) {
-                    uint32_t gb[2][4];
-                    int i0v[2], xav[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int it = it0 + u * kLdsThreads;
-                        const int itc = it < items ? it : it0;
-                        const int fq = itc % quads, bq = itc / quads;
-                        i0v[u] = bq * 4;
-                        xav[u] = it < items ? x0 + fq * 4 : a.width;      // past the image: nothing is stored
-#pragma unroll
-                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
-                    }
-                    uint32_t px[2][4][4];
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-#pragma unroll
-                            for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int xa = xav[u];
-                        if (xa >= a.width) continue;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int i = i0v[u] + j;
-                            const int y = (N / 2 - i) & (N - 1);
-                            uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
-                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
-                                *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 4; k++)
-                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
-                            }
-                        }
-                    }
-                }
-            } else {
-                // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
-                const int items = group_frames * (N / 4);
-                for (int it = tid; it < items; it += kLdsThreads) {
-                    const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
-                    const int xa = x0 + f;
-                    if (xa >= a.width) continue;
-                    const unsigned char *row = s_tile + f * tile_pitch;
-                    uint32_t px[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) px[k] = s_lut[row[(c4 + k + N / 2 + 1) & (N - 1)]];
-                    uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
-                    *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
-                }
-            }
-        }
+        drain(x0);
         __syncthreads();   // tile and s_mm are reused by the next group
+#endif
     }
 
+#if SP_LATE_DRAIN
+    if (drain_x0 >= 0) {   // last group
+        __syncthreads();
+        drain(drain_x0);
+        __syncthreads();
+    }
+#endif
     // ---- flush histograms ----------------------------------------------------------------------------------------
     if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
