@@ -331,6 +331,9 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
 #ifndef SP_LATE_DRAIN
 #define SP_LATE_DRAIN 1
 #endif
+#ifndef SP_DRAIN_PARTS
+#define SP_DRAIN_PARTS 2
+#endif
 #ifndef SP_EPI_CHUNK
 #define SP_EPI_CHUNK 8
 #endif
@@ -459,8 +462,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
     // ---- a finished group: per-frame extremes to HBM, tile -> RGBA (between two workgroup barriers) ---------------------------
-    auto drain = [&](const int x0) {
-        if (tid < group_frames) {
+    // part / nparts: the write-out can be issued in slices between the passes of the next frame, so that the stores drain
+    // into HBM while the SIMDs compute (the extremes go with slice 0)
+    auto drain = [&](const int x0, const int part, const int nparts) {
+        if (part == 0 && tid < group_frames) {
             if (x0 + tid < a.width) {
                 unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
 #pragma unroll
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 const int items = (N / 4) * quads;
                 // two items per thread and iteration: all tile reads first, then the LUT reads, then the stores, so the
                 // LDS latencies of the write-out overlap instead of adding up
-                for (int it0 = tid; it0 < items; it0 += 2 * kLdsThreads) {
+                for (int it0 = tid + part * 2 * kLdsThreads; it0 < items; it0 += nparts * 2 * kLdsThreads) {
                     uint32_t gb[2][4];
                     int i0v[2], xav[2];
 #pragma unroll
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             } else {
                 // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
                 const int items = group_frames * (N / 4);
-                for (int it = tid; it < items; it += kLdsThreads) {
+                for (int it = tid + part * kLdsThreads; it < items; it += nparts * kLdsThreads) {
                     const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
                     const int xa = x0 + f;
                     if (xa >= a.width) continue;
@@ -600,8 +605,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
+#if SP_LATE_DRAIN
+            if (SP_DRAIN_PARTS > 1 && drain_x0 >= 0) {   // every wave has finished the previous group: first slice of its write-out
+                __syncthreads();
+                drain(drain_x0, 0, SP_DRAIN_PARTS);
+            }
+#endif
             if constexpr (STAGED) fft_pass_staged<0, 1, 4>(re, im, tl, s_tw, stage_tw);
             else fft_pass<0, 1, 4>(re, im, tw0);
+#if SP_LATE_DRAIN
+            if (SP_DRAIN_PARTS >= 3 && drain_x0 >= 0) drain(drain_x0, 1, SP_DRAIN_PARTS);
+#endif
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
@@ -612,6 +626,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
+#if SP_LATE_DRAIN
+                if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
+#endif
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
@@ -674,9 +691,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
 
 #if SP_LATE_DRAIN
-            if (drain_x0 >= 0) {   // the previous group's tile: all waves have finished it once they reach this point
-                __syncthreads();
-                drain(drain_x0);
+            if (drain_x0 >= 0) {   // the previous group's tile: last slice, then the tile is free again
+                if (SP_DRAIN_PARTS == 1) __syncthreads();
+                drain(drain_x0, SP_DRAIN_PARTS - 1, SP_DRAIN_PARTS);
                 __syncthreads();
                 drain_x0 = -1;
             }
@@ -772,7 +789,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         drain_x0 = x0;   // drained ahead of the next epilogue (or after the loop): early waves start their next frame first
 #else
         __syncthreads();   // tile complete
-        drain(x0);
+        drain(x0, 0, 1);
         __syncthreads();   // tile and s_mm are reused by the next group
 #endif
     }
@@ -780,7 +797,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #if SP_LATE_DRAIN
     if (drain_x0 >= 0) {   // last group
         __syncthreads();
-        drain(drain_x0);
+        drain(drain_x0, 0, 1);
         __syncthreads();
     }
 #endif
