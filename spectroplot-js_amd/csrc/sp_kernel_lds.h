@@ -794,40 +794,39 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #endif
     }
 
-#if SP_LATE_DRAIN
-    if (drain_x0 >= 0) {   // last group
-        __syncthreads();
-        drain(drain_x0, 0, 1);
-        __syncthreads();
-    }
-#endif
-    // ---- flush histograms ----------------------------------------------------------------------------------------
-    if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
-        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
-        if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
-    }
+    // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
     if ((tid & 63) == 0) {                               // per-wave counters of the clipped / end bins
         if (cnt_g0) atomicAdd(&s_chist[0], cnt_g0);
         if (cnt_gmax) atomicAdd(&s_chist[cmax], cnt_gmax);
         if (cnt_cb_last) atomicAdd(&s_cbhist[0], cnt_cb_last);                 // level 0 = bin 999
         if (cnt_cb0) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb0);       // specials = bin 0
     }
-    __syncthreads();
-    if (tid == 0) {                                      // one pair of device atomics per workgroup (dBfs range, k_finish_frames)
-        if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
-        if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
-    }
-    for (int i = tid; i < a.lut_len; i += kLdsThreads)
-    {
+    __syncthreads();   // LDS histograms and the last tile are complete
+    // the device atomics are issued ahead of the last write-out, so they complete under its HBM burst
+    for (int i = tid; i < a.lut_len; i += kLdsThreads) {
         unsigned int v = 0;
         for (int c = 0; c < kHistCopies; c++) v += s_chist[i + c * a.lut_len];
         if (v) atomicAdd(&a.c_hist[i], (unsigned long long)v);
     }
-    for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads)
-    {
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kLdsThreads) {
         unsigned int v = 0;
         for (int c = 0; c < kHistCopies; c++) v += s_cbhist[i + c * SP_CB_HIST_SIZE];
         if (v) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)v);
+    }
+#if SP_LATE_DRAIN
+    if (drain_x0 >= 0) {   // last group
+        drain(drain_x0, 0, 1);
+        __syncthreads();
+    }
+#endif
+    if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
+        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
+        if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
+    }
+    __syncthreads();
+    if (tid == 0) {                                      // one pair of device atomics per workgroup (dBfs range, k_finish_frames)
+        if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
+        if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
     }
 }
 
