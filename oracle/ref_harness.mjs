@@ -297,6 +297,56 @@ const run = async () => {
             window_key_order: Object.keys(windows) }, null, 0))
     }
 
+
+    // ---- side-output consumers KAT (lib/spectroplot.js drawColorRamp :620-684, drawHistograms :686-757) ------------------
+    // The methods are run unmodified on a stand-in `this` whose canvas context records the calls it receives.
+    {
+        const saved = console.log
+        console.log = () => {}
+        globalThis.window = { File: 1, FileReader: 1, FileList: 1, Blob: 1, addEventListener() {}, dispatchEvent() {} }
+        globalThis.alert = () => {}
+        globalThis.navigator = { hardwareConcurrency: 2 }
+        globalThis.Event = globalThis.Event || function Event() {}
+        const mkctx = () => {
+            const calls = []
+            const ctx = { calls, font: '', fillStyle: '', strokeStyle: '', lineWidth: 0,
+                createImageData: (w, h) => ({ data: new Uint8ClampedArray(4 * w * h), width: w, height: h }),
+                putImageData(d, x, y) { calls.push(['putImageData', x, y, d.width, d.height, Buffer.from(d.data.buffer).toString('base64')]) },
+                fillRect(x, y, w, h) { calls.push(['fillRect', x, y, w, h, this.fillStyle]) },
+                fillText(t, x, y) { calls.push(['fillText', t, x, y]) },
+                beginPath() { calls.push(['beginPath']) }, moveTo(x, y) { calls.push(['moveTo', x, y]) },
+                lineTo(x, y) { calls.push(['lineTo', x, y]) },
+                fill() { calls.push(['fill', this.fillStyle]) }, stroke() { calls.push(['stroke', this.strokeStyle, this.lineWidth]) } }
+            return ctx
+        }
+        globalThis.document = { createElement: () => ({ width: 0, height: 0, getContext: () => mkctx() }),
+            querySelector: () => null, querySelectorAll: () => [], getElementsByClassName: () => [], addEventListener() {} }
+        const SP = await import('./lib/spectroplot.js')
+        const proto = SP.Spectroplot.prototype
+        const out = []
+        for (const c of spec.consumer_kat.cases) {
+            const cm = cmaps[c.cmap].map(e => e.slice(0, 3))
+            const ctx = mkctx()
+            const canvas = { width: 0, height: 0, style: {}, parentNode: { style: {} }, getContext: () => ctx }
+            const self = { gain: c.gain, range: c.range, height: c.height, fftN: c.height, histWidth: c.histWidth, cmap: cm,
+                opts: { dbfsWidth: 60, timeHeight: 20, rampWidth: c.rampWidth, rampTop: c.rampTop, histLeft: c.histLeft },
+                theme: { rampFill: '#666', histoLine: 2, histoStroke: '#b0b', histoFill: 'rgba(187,0,187,0.2)', dbfsLine: 2,
+                    dbfsStroke: '#999', dbfsFill: 'rgba(153,153,153,0.2)' },
+                parent: { getElementsByClassName: () => [canvas] } }
+            proto.drawColorRamp.call(self)
+            const ramp = ctx.calls.slice()
+            ctx.calls.length = 0
+            // deterministic histograms
+            const c_hist = new Array(cm.length), cB_hist = new Array(1000)
+            for (let i = 0; i < cm.length; i++) c_hist[i] = siggen.hash(c.seed, i) % 5000
+            for (let i = 0; i < 1000; i++) cB_hist[i] = siggen.hash(c.seed ^ 0x55, i) % 70000
+            proto.drawHistograms.call(self, c_hist, cB_hist)
+            out.push({ name: c.name, canvas: { width: canvas.width, height: canvas.height }, ramp, hist: ctx.calls.slice() })
+        }
+        console.log = saved
+        fs.writeFileSync(path.join(outdir, 'consumers.json'), JSON.stringify(out, null, 0))
+    }
+
     fs.writeFileSync(path.join(outdir, 'provenance.json'), JSON.stringify({
         generated_by: 'oracle/gen_golden.js + oracle/ref_harness.mjs',
         reference: 'triq-org/spectroplot-js lib/worker.js (v1.2.1, /root/reference)',

@@ -3,4 +3,5 @@
 const { HipWorker, packLut } = require('./hip_worker.js')
 const { renderSliced } = require('./render_file.js')
 const params = require('./params.js')
-module.exports = Object.assign({ HipWorker, packLut, renderSliced }, params)
+const consumers = require('./consumers.js')
+module.exports = Object.assign({ HipWorker, packLut, renderSliced }, params, consumers)

@@ -29,6 +29,14 @@ def test_caller_side_parameter_helpers_match_reference():
     assert "params checks ok" in out.stdout
 
 
+def test_side_output_consumers_match_reference_draw_calls():
+    """js/consumers.js (colour ramp, dBfs markers, histogram outlines) call for call against the reference's drawColorRamp /
+    drawHistograms run on a recording 2-D context (tests/golden/consumers.json)."""
+    out = _node("check_consumers.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "consumers checks ok" in out.stdout
+
+
 @pytest.mark.gpu
 def test_hip_worker_reproduces_golden_vectors():
     out = _node("check_hip_worker.js")
