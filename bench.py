@@ -125,30 +125,45 @@ def main():
     rgba = torch.empty(4 * W * n, dtype=torch.uint8, device=dev)
     rgba_ptr = 0 if args.no_rgba else rgba.data_ptr()
     gauges = torch.empty(3 * W, dtype=torch.uint8, device=dev)
-    hists = torch.zeros(len(lut) + 1000, dtype=torch.int64, device=dev)
-    minmax = torch.zeros(2, dtype=torch.float64, device=dev)
+    # side outputs of one slice as one record [c_hist | cB_hist | dBfs_min, dBfs_max as f64 bits]: the library writes straight
+    # into it.  Two records in rotation: the all-gather of step k (RCCL's stream) overlaps the frame loop of step k+1.
+    L = len(lut)
+    P = L + 1000 + 2
+    records = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(world * P, dtype=torch.int64, device=dev) for _ in range(2)] if world > 1 else None
+    merged_buf = torch.zeros(P, dtype=torch.int64, device=dev)
+    state = {"k": 0, "pending": None}
 
-    P = len(lut) + 1000 + 2
-    payload = torch.zeros(P, dtype=torch.int64, device=dev)          # [c_hist | cB_hist | dBfs_min, dBfs_max as f64 bits]
-    gathered = torch.zeros(world * P, dtype=torch.int64, device=dev) if world > 1 else None
-    merged = {}
+    def run_slice(rec):
+        p = rec.data_ptr()
+        plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                     p, p + 8 * L, p + 8 * (L + 1000))
+
+    def merge(slot):
+        # the caller's merge of the slices' side outputs (lib/spectroplot.js:1229-1238), on device
+        p = merged_buf.data_ptr()
+        ctx.merge_replies(gathered[slot].data_ptr(), world, L, p, p + 8 * L, p + 8 * (L + 1000))
 
     def step():
-        plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
-                     hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
+        slot = state["k"] & 1
+        state["k"] += 1
+        run_slice(records[slot])
         if dist is not None:
-            # the caller's merge of the side outputs (lib/spectroplot.js:1229-1238) as ONE collective: every rank gathers
-            # all ranks' histograms and dBfs ranges (10 KB each) and reduces them locally (sums, min, max)
-            payload[:P - 2] = hists
-            payload[P - 2:] = minmax.view(torch.int64)
-            dist.all_gather_into_tensor(gathered, payload)
-            g = gathered.view(world, P)
-            merged["hists"] = g[:, :P - 2].sum(dim=0)
-            mm = g[:, P - 2:].contiguous().view(torch.float64).view(world, 2)
-            merged["min"] = mm[:, 0].min()
-            merged["max"] = mm[:, 1].max()
-        else:
-            merged["hists"] = hists
+            # ONE collective per render: every rank gathers all ranks' records (10 KB each); it is queued behind this
+            # step's kernels and runs while the next step computes.  The previous step's gather has long finished: merge it.
+            work = dist.all_gather_into_tensor(gathered[slot], records[slot], async_op=True)
+            if state["pending"] is not None:
+                pw, pslot = state["pending"]
+                pw.wait()
+                merge(pslot)
+            state["pending"] = (work, slot)
+
+    def finish_pending():
+        if state["pending"] is not None:
+            pw, pslot = state["pending"]
+            pw.wait()
+            merge(pslot)
+            state["pending"] = None
 
     def sync():
         if dist is not None:
@@ -157,13 +172,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish_pending()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish_pending()                                          # the last render's merge belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
-    hsum = int(merged["hists"][:len(lut)].sum().item())       # all slices after the merge
+    final = merged_buf if dist is not None else records[(state["k"] - 1) & 1]
+    hsum = int(final[:L].sum().item())                        # all slices after the merge
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,8 +193,7 @@ def main():
     for _ in range(40):
         # a short back-to-back batch, as in the timed region; the events bracket the batch's last frame-loop kernel
         for _ in range(max(2, min(args.steps, 8))):
-            plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
-                         hists.data_ptr(), hists.data_ptr() + 8 * len(lut), minmax.data_ptr())
+            run_slice(records[0])
         torch.cuda.synchronize()
         kms.append(ctx.last_kernel_ms())
     ctx.enable_timing(False)

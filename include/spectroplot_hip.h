@@ -86,8 +86,8 @@ typedef struct sp_reply {
     uint8_t *gauge_mins;     /* [width] */
     uint8_t *gauge_maxs;     /* [width] */
     uint8_t *gauge_amps;     /* [width] */
-    uint64_t *c_hist;        /* [lut_len]  (sp_plan_execute ADDS into it; zero it first) */
-    uint64_t *cb_hist;       /* [SP_CB_HIST_SIZE]  (likewise) */
+    uint64_t *c_hist;        /* [lut_len]  overwritten with the counts of this request */
+    uint64_t *cb_hist;       /* [SP_CB_HIST_SIZE]  likewise */
     double *dbfs_minmax;     /* [2] = {dBfs_min, dBfs_max} */
 } sp_reply;
 
@@ -137,6 +137,14 @@ void sp_plan_destroy(sp_plan *plan);
  * reference's worker returns fresh arrays (lib/worker.js:40-41); the caller sums the slices (lib/spectroplot.js:1229-1238).
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
+/*
+ * The caller's merge of slice replies (lib/spectroplot.js:1229-1238) on device-resident side outputs: `count` records of
+ * [c_hist u64[lut_len] | cB_hist u64[SP_CB_HIST_SIZE] | dBfs_min f64 | dBfs_max f64] laid end to end at d_records (what an
+ * all-gather of the slices' records delivers) are reduced to element-wise sums and min / max.  Outputs are device pointers;
+ * any may be NULL.  Asynchronous on the context's stream.
+ */
+int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int32_t lut_len, uint64_t *d_c_hist, uint64_t *d_cb_hist,
+                     double *d_dbfs_minmax);
 /* Name of the kernel variant sp_plan_execute launches ("lds_r16", "scratch_radix2"). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
 /* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16. */

@@ -95,6 +95,7 @@ class Library:
         L.sp_synth_trinoise.argtypes = [vp, vp, i32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dbl, dbl]
         L.sp_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_context_enable_timing.argtypes = [vp, i32]
+        L.sp_merge_replies.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
 
     @classmethod
@@ -185,6 +186,11 @@ class Context:
 
     def enable_timing(self, on=True):
         self._chk(self.lib.L.sp_context_enable_timing(self.h, int(on)))
+
+    def merge_replies(self, d_records, count, lut_len, d_c_hist=0, d_cb_hist=0, d_minmax=0):
+        """Device-side merge of `count` slice records [c_hist | cB_hist | dBfs_min, dBfs_max] (the caller's merge, spectroplot.js:1229-1238)."""
+        self._chk(self.lib.L.sp_merge_replies(self.h, C.c_void_p(d_records), int(count), int(lut_len), C.c_void_p(d_c_hist or None),
+                                              C.c_void_p(d_cb_hist or None), C.c_void_p(d_minmax or None)))
 
     def event_pair_overhead_ms(self):
         ms = C.c_float()

@@ -649,6 +649,45 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     return SP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------- merge of slice replies
+
+__global__ void k_merge_replies(const unsigned long long *rec, int count, int lut_len, unsigned long long *c_hist, unsigned long long *cb_hist,
+                                double *minmax)
+{
+    const int stride = lut_len + SP_CB_HIST_SIZE + 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < lut_len + SP_CB_HIST_SIZE) {
+        unsigned long long s = 0;
+        for (int r = 0; r < count; r++) s += rec[(size_t)r * stride + i];                           // spectroplot.js:1232-1238
+        if (i < lut_len) {
+            if (c_hist) c_hist[i] = s;
+        } else if (cb_hist) {
+            cb_hist[i - lut_len] = s;
+        }
+    } else if (i < stride && minmax) {
+        const int k = i - (lut_len + SP_CB_HIST_SIZE);                                              // 0: min, 1: max
+        double v = __longlong_as_double((long long)rec[i]);
+        for (int r = 1; r < count; r++) {
+            const double w = __longlong_as_double((long long)rec[(size_t)r * stride + i]);
+            v = k == 0 ? (w < v ? w : v) : (w > v ? w : v);                                         // the `<` / `>` updates of :1230-1231
+        }
+        minmax[k] = v;
+    }
+}
+
+extern "C" int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int32_t lut_len, uint64_t *d_c_hist,
+                                uint64_t *d_cb_hist, double *d_dbfs_minmax)
+{
+    if (!ctx || !d_records || count < 1 || lut_len < 1 || lut_len > SP_MAX_LUT) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int total = lut_len + SP_CB_HIST_SIZE + 2;
+    hipLaunchKernelGGL(k_merge_replies, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)d_records, (int)count, (int)lut_len, (unsigned long long *)d_c_hist,
+                       (unsigned long long *)d_cb_hist, d_dbfs_minmax);
+    SP_HIP(ctx, hipGetLastError());
+    return SP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- host-buffer render
 
 static bool same_request(const sp_plan *p, const sp_request *r)

@@ -396,3 +396,29 @@ def test_reply_is_overwritten_not_accumulated(pkg, ctx):
         for p in ptrs + [d_in]:
             ctx.free(p)
         plan.close()
+
+
+def test_merge_replies_matches_callers_merge(pkg, ctx):
+    """sp_merge_replies against the reference caller's merge (element-wise histogram sums, running min / max of the dBfs range,
+    lib/spectroplot.js:1229-1238) on random records."""
+    rs = np.random.RandomState(11)
+    for count, L in ((1, 256), (2, 256), (8, 64), (5, 300)):
+        P = L + 1000 + 2
+        rec = np.zeros((count, P), dtype=np.uint64)
+        rec[:, :L + 1000] = rs.randint(0, 1 << 40, size=(count, L + 1000)).astype(np.uint64)
+        mins = -rs.rand(count) * 150.0
+        maxs = -rs.rand(count) * 100.0 - 1.0
+        mins[0], maxs[-1] = 0.0, -200.0                        # the worker's initial values are legal replies
+        rec[:, P - 2] = mins.view(np.uint64)
+        rec[:, P - 1] = maxs.view(np.uint64)
+        d_rec, d_out = ctx.alloc(rec.nbytes), ctx.alloc(8 * P)
+        ctx.upload(d_rec, rec.view(np.uint8).reshape(-1))
+        ctx.memset(d_out, 0xEE, 8 * P)
+        ctx.merge_replies(d_rec, count, L, d_out, d_out + 8 * L, d_out + 8 * (L + 1000))
+        ctx.synchronize()
+        out = ctx.download(d_out, 8 * P, np.uint64)
+        assert np.array_equal(out[:L + 1000], rec[:, :L + 1000].sum(axis=0))
+        mm = out[L + 1000:].view(np.float64)
+        assert mm[0] == mins.min() and mm[1] == maxs.max()
+        ctx.free(d_rec)
+        ctx.free(d_out)
