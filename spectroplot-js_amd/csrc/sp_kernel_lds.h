@@ -144,7 +144,10 @@ __device__ inline void load_pass_tw(PassTw<WS, S0, S1> &t, int tl, const double2
 }
 
 // One register pass: stages S0..S1 (1-based; stage s has size 2^s) inside window [WS, WS+4).
-template <int WS, int S0, int S1>
+// TRIV: the butterflies of the first pass whose twiddle is entry 0 of its stage, (cos 0, sin 0) = (1, 0) exactly, skip the
+// four products: x*1 + y*0 = x bit for bit when x and y are finite (only the sign of a zero can differ, and no output depends
+// on it); with an infinite or NaN y the product y*0 is NaN, so the caller enables TRIV only for frames without such samples.
+template <int WS, int S0, int S1, bool TRIV = false>
 __device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw<WS, S0, S1> &t)
 {
     int base = 0;
@@ -158,8 +161,9 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw
             const double2 w = t.w[base + (e0 & ((1 << u) - 1))];
             const double c = w.x, sn = w.y;
             const double rl = re[e1], il = im[e1];
-            const double tpre = rl * c + il * sn;          // fft_nayuki.js:80
-            const double tpim = il * c - rl * sn;          // fft_nayuki.js:81  (-rl*sn + il*c)
+            const bool unit = TRIV && WS == 0 && (e0 & ((1 << u) - 1)) == 0;   // compile-time after unrolling
+            const double tpre = unit ? rl : rl * c + il * sn;          // fft_nayuki.js:80
+            const double tpim = unit ? il : il * c - rl * sn;          // fft_nayuki.js:81  (-rl*sn + il*c)
             const double rj = re[e0], ij = im[e0];
             re[e1] = rj - tpre;
             im[e1] = ij - tpim;
@@ -297,8 +301,9 @@ __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start
     }
 }
 
+// Returns true if the frame may hold infinities or NaNs (float formats; integer formats never do).
 template <int FMT, int NHI>
-__device__ inline void decode_frame(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI], const double (&win)[16], double (&re)[16],
+__device__ inline bool decode_frame(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI], const double (&win)[16], double (&re)[16],
                                     double (&im)[16])
 {
 #pragma unroll
@@ -308,6 +313,9 @@ __device__ inline void decode_frame(const uint32_t (&lo)[16], const uint32_t (&h
         re[e] = win[e] * vi;                                                   // worker.js:73-74
         im[e] = win[e] * vq;
     }
+    // A float capture may hold them, and telling costs as much as the products it would save (32 v_cmp_class per lane-frame
+    // plus a second copy of the first pass: measured 28 % slower), so float frames keep the full butterflies.
+    return FMT == SP_FMT_CF32 || FMT == SP_FMT_CF64;
 }
 
 
@@ -333,6 +341,12 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
 #endif
 #ifndef SP_DRAIN_PARTS
 #define SP_DRAIN_PARTS 2
+#endif
+#ifndef SP_TW0_LATE
+#define SP_TW0_LATE 1
+#endif
+#ifndef SP_UNIT_TWIDDLES
+#define SP_UNIT_TWIDDLES 1
 #endif
 #ifndef SP_EPI_CHUNK
 #define SP_EPI_CHUNK 8
@@ -561,23 +575,26 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 
             double re[16], im[16];
             double win[16];
+            bool nonfinite = true;   // wave-uniform; only the register-load variants can rule it out
 #pragma unroll
             for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
             PassTw<0, 1, STAGED ? 0 : 4> tw0;
-            if constexpr (!STAGED) load_pass_tw(tw0, tl, s_tw, stage_tw);   // lane-uniform (broadcast reads), in flight during the decode
+            // lane-uniform (broadcast reads); in flight during the decode where the registers allow it
+            constexpr bool TW0_LATE = SP_TW0_LATE && PFB != 8;
+            if constexpr (!STAGED && !TW0_LATE) load_pass_tw(tw0, tl, s_tw, stage_tw);
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
                 if constexpr (PFB == 2) {
-                    if (format == SP_FMT_CU8) decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
-                    else decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU8) nonfinite = decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
                 } else if constexpr (PFB == 4) {
-                    if (format == SP_FMT_CU16) decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im);
-                    else decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU16) nonfinite = decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im);
                 } else {
-                    if (format == SP_FMT_CU32) decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im);
-                    else if (format == SP_FMT_CS32) decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im);
-                    else decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU32) nonfinite = decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im);
+                    else if (format == SP_FMT_CS32) nonfinite = decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im);
                 }
                 if (xn >= 0) request(xn);           // in flight during this frame's butterflies
             } else {
@@ -611,8 +628,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 drain(drain_x0, 0, SP_DRAIN_PARTS);
             }
 #endif
-            if constexpr (STAGED) fft_pass_staged<0, 1, 4>(re, im, tl, s_tw, stage_tw);
-            else fft_pass<0, 1, 4>(re, im, tw0);
+            if constexpr (STAGED) {
+                fft_pass_staged<0, 1, 4>(re, im, tl, s_tw, stage_tw);
+            } else {
+                if constexpr (TW0_LATE) load_pass_tw(tw0, tl, s_tw, stage_tw);
+#if SP_UNIT_TWIDDLES
+                // (not in the 8-byte variants: cf32 needs the full butterflies, and a second copy of the pass for cu32 / cs32
+                // costs the cf32 path its registers)
+                if (PFB != 8 && !nonfinite) fft_pass<0, 1, 4, true>(re, im, tw0);   // 15 of the 32 butterflies without their products
+                else
+#endif
+                fft_pass<0, 1, 4>(re, im, tw0);
+            }
 #if SP_LATE_DRAIN
             if (SP_DRAIN_PARTS >= 3 && drain_x0 >= 0) drain(drain_x0, 1, SP_DRAIN_PARTS);
 #endif
