@@ -13,7 +13,7 @@ sw = pkg.parse_format(fmt)[1]
 win, weight = pkg.window("blackmanHarris", n)
 i = np.arange(256)
 lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
-plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, bool(int(os.environ.get("SP_CH", "0"))))
 plan.force_kernel(kern)
 Smax = 24576 * n
 d_in = ctx.alloc(Smax * sw)
