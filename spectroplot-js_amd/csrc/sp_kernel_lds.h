@@ -360,7 +360,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     constexpr int T = N / 16;                       // threads per frame
     constexpr int FPB = kLdsThreads / T;            // frames per round
     constexpr bool BLOCK_SYNC = T > 64;
-    constexpr int WPF = T > 64 ? T / 64 : 1;        // waves per frame
     constexpr int NPASS = (LOG2N + 3) / 4;
     // Twiddles of a pass are read as one batch ahead of its re-distribution, except in the generic-loader variants, whose
     // format switch and bounds-checked loads leave no registers for the batch (SP_STAGED_TW: experiment switch).
