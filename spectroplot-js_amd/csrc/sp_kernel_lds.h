@@ -27,6 +27,10 @@
 
 #include "sp_kernels_common.h"
 
+#ifndef SP_LDS_BARRIER
+#define SP_LDS_BARRIER 1   // experiment switch: 0 = __syncthreads() everywhere
+#endif
+
 namespace spk {
 
 constexpr int kLdsThreads = 512;
@@ -174,11 +178,23 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw
     }
 }
 
+// Workgroup barrier for data that travels through LDS only.  __syncthreads() also waits for every outstanding global-memory
+// operation of the wave (s_waitcnt vmcnt(0)): here that would be the in-flight input prefetch at every exchange of the large-n
+// variants and, after a write-out, the whole HBM store burst.  Nothing in this kernel hands global data from wave to wave.
+__device__ inline void lds_barrier()
+{
+#if SP_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 template <bool BLOCK_SYNC>
 __device__ inline void frame_sync()
 {
     if constexpr (BLOCK_SYNC) {
-        __syncthreads();
+        lds_barrier();
     } else {
         // The frame lives in one wave and the LDS executes a wave's operations in order, so the hardware needs nothing;
         // only the compiler must not move LDS accesses across this point.  (A wavefront-scope fence is NOT used here:
@@ -463,7 +479,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         s_mm[2 * i] = 0x7ff0000000000000ull;
         s_mm[2 * i + 1] = 0ull;
     }
-    __syncthreads();
+    lds_barrier();
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
 #if SP_LATE_DRAIN
             if (SP_DRAIN_PARTS > 1 && drain_x0 >= 0) {   // every wave has finished the previous group: first slice of its write-out
-                __syncthreads();
+                lds_barrier();
                 drain(drain_x0, 0, SP_DRAIN_PARTS);
             }
 #endif
@@ -718,9 +734,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 
 #if SP_LATE_DRAIN
             if (drain_x0 >= 0) {   // the previous group's tile: last slice, then the tile is free again
-                if (SP_DRAIN_PARTS == 1) __syncthreads();
+                if (SP_DRAIN_PARTS == 1) lds_barrier();
                 drain(drain_x0, SP_DRAIN_PARTS - 1, SP_DRAIN_PARTS);
-                __syncthreads();
+                lds_barrier();
                 drain_x0 = -1;
             }
 #endif
@@ -814,9 +830,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #if SP_LATE_DRAIN
         drain_x0 = x0;   // drained ahead of the next epilogue (or after the loop): early waves start their next frame first
 #else
-        __syncthreads();   // tile complete
+        lds_barrier();   // tile complete
         drain(x0, 0, 1);
-        __syncthreads();   // tile and s_mm are reused by the next group
+        lds_barrier();   // tile and s_mm are reused by the next group
 #endif
     }
 
@@ -827,7 +843,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         if (cnt_cb_last) atomicAdd(&s_cbhist[0], cnt_cb_last);                 // level 0 = bin 999
         if (cnt_cb0) atomicAdd(&s_cbhist[SP_CB_HIST_SIZE - 1], cnt_cb0);       // specials = bin 0
     }
-    __syncthreads();   // LDS histograms and the last tile are complete
+    lds_barrier();   // LDS histograms and the last tile are complete
     // the device atomics are issued ahead of the last write-out, so they complete under its HBM burst
     for (int i = tid; i < a.lut_len; i += kLdsThreads) {
         unsigned int v = 0;
@@ -842,14 +858,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #if SP_LATE_DRAIN
     if (drain_x0 >= 0) {   // last group
         drain(drain_x0, 0, 1);
-        __syncthreads();
+        lds_barrier();
     }
 #endif
     if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
         if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {                                      // one pair of device atomics per workgroup (dBfs range, k_finish_frames)
         if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
         if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
