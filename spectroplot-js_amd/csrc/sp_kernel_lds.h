@@ -27,8 +27,20 @@
 
 #include "sp_kernels_common.h"
 
-#ifndef SP_LDS_BARRIER
-#define SP_LDS_BARRIER 1   // experiment switch: 0 = __syncthreads() everywhere
+
+// Compile-time tunables (tools/build_variant.sh builds a library variant with other values; tools/ab_kernel.sh compares
+// variants on one GPU in one call).  The defaults are the measured best for config 2 on MI355X.
+#ifndef SP_STAGED_TW
+#define SP_STAGED_TW 0     // 1: twiddles read stage by stage everywhere (default: one batch per pass, except the generic loaders)
+#endif
+#ifndef SP_DRAIN_PARTS
+#define SP_DRAIN_PARTS 2   // slices of a group's write-out around the passes of the next frame (1..4)
+#endif
+#ifndef SP_EPI_CHUNK
+#define SP_EPI_CHUNK 8     // bins whose edge reads are in flight together (4, 8, 16)
+#endif
+#ifndef SP_HIST_COPIES
+#define SP_HIST_COPIES 1   // LDS histogram copies dealt over lanes (1, 2)
 #endif
 
 namespace spk {
@@ -37,9 +49,6 @@ constexpr int kLdsThreads = 512;
 constexpr int kLdsMinLog2 = 6, kLdsMaxLog2 = 13;
 constexpr int kLdsMaxLut = 256;      // colour indices travel through a byte tile
 constexpr float kLdsMaxGrayB = 2000.0f;   // first-guess slope bound that keeps the one-compare correction exact
-#ifndef SP_HIST_COPIES
-#define SP_HIST_COPIES 1
-#endif
 constexpr int kHistCopies = SP_HIST_COPIES;   // LDS histogram copies (lanes are dealt over them): fewer same-word atomics
 constexpr int kTilePad = 4;   // tile row pitch = n + 4 bytes: conflict-free dword reads across 8 frame quads
 
@@ -183,11 +192,7 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw
 // variants and, after a write-out, the whole HBM store burst.  Nothing in this kernel hands global data from wave to wave.
 __device__ inline void lds_barrier()
 {
-#if SP_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 
 template <bool BLOCK_SYNC>
@@ -349,24 +354,6 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
     }
 }
 
-#ifndef SP_STAGED_TW
-#define SP_STAGED_TW 0
-#endif
-#ifndef SP_LATE_DRAIN
-#define SP_LATE_DRAIN 1
-#endif
-#ifndef SP_DRAIN_PARTS
-#define SP_DRAIN_PARTS 2
-#endif
-#ifndef SP_TW0_LATE
-#define SP_TW0_LATE 1
-#endif
-#ifndef SP_UNIT_TWIDDLES
-#define SP_UNIT_TWIDDLES 1
-#endif
-#ifndef SP_EPI_CHUNK
-#define SP_EPI_CHUNK 8
-#endif
 
 template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
@@ -578,7 +565,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             }
         }
     };
-    int drain_x0 = -1;   // SP_LATE_DRAIN: group whose tile is still waiting for its write-out
+    int drain_x0 = -1;   // first frame of the group whose tile is still waiting for its write-out
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = g * group_frames;
         for (int r = 0; r < rounds; r++) {
@@ -595,7 +582,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
             PassTw<0, 1, STAGED ? 0 : 4> tw0;
             // lane-uniform (broadcast reads); in flight during the decode where the registers allow it
-            constexpr bool TW0_LATE = SP_TW0_LATE && PFB != 8;
+            constexpr bool TW0_LATE = PFB != 8;
             if constexpr (!STAGED && !TW0_LATE) load_pass_tw(tw0, tl, s_tw, stage_tw);
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
@@ -637,27 +624,21 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;   // still a global-memory pointer for the compiler (no flat loads)
-#if SP_LATE_DRAIN
             if (SP_DRAIN_PARTS > 1 && drain_x0 >= 0) {   // every wave has finished the previous group: first slice of its write-out
                 lds_barrier();
                 drain(drain_x0, 0, SP_DRAIN_PARTS);
             }
-#endif
             if constexpr (STAGED) {
                 fft_pass_staged<0, 1, 4>(re, im, tl, s_tw, stage_tw);
             } else {
                 if constexpr (TW0_LATE) load_pass_tw(tw0, tl, s_tw, stage_tw);
-#if SP_UNIT_TWIDDLES
                 // (not in the 8-byte variants: cf32 needs the full butterflies, and a second copy of the pass for cu32 / cs32
                 // costs the cf32 path its registers)
                 if (PFB != 8 && !nonfinite) fft_pass<0, 1, 4, true>(re, im, tw0);   // 15 of the 32 butterflies without their products
                 else
-#endif
                 fft_pass<0, 1, 4>(re, im, tw0);
             }
-#if SP_LATE_DRAIN
             if (SP_DRAIN_PARTS >= 3 && drain_x0 >= 0) drain(drain_x0, 1, SP_DRAIN_PARTS);
-#endif
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
@@ -668,9 +649,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
-#if SP_LATE_DRAIN
                 if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
-#endif
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
@@ -732,14 +711,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 }
             }
 
-#if SP_LATE_DRAIN
             if (drain_x0 >= 0) {   // the previous group's tile: last slice, then the tile is free again
                 if (SP_DRAIN_PARTS == 1) lds_barrier();
                 drain(drain_x0, SP_DRAIN_PARTS - 1, SP_DRAIN_PARTS);
                 lds_barrier();
                 drain_x0 = -1;
             }
-#endif
             // ---- |X|^2 -> indices ---------------------------------------------------------------------------
             // The first guess floor(a + b*log2(abs2)) is biased half a step low, so the exact index is the guess or
             // the guess + 1; one comparison against the exact edge decides (edges: sp_host.h Thresholds).
@@ -827,13 +804,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
         }
-#if SP_LATE_DRAIN
         drain_x0 = x0;   // drained ahead of the next epilogue (or after the loop): early waves start their next frame first
-#else
-        lds_barrier();   // tile complete
-        drain(x0, 0, 1);
-        lds_barrier();   // tile and s_mm are reused by the next group
-#endif
     }
 
     // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
@@ -855,12 +826,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
         for (int c = 0; c < kHistCopies; c++) v += s_cbhist[i + c * SP_CB_HIST_SIZE];
         if (v) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)v);
     }
-#if SP_LATE_DRAIN
     if (drain_x0 >= 0) {   // last group
         drain(drain_x0, 0, 1);
         lds_barrier();
     }
-#endif
     if (tid < group_frames) {                            // extreme |X|^2 of this workgroup's frames: s_mm[0..1] are {+inf, 0} again
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
         if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
