@@ -679,34 +679,47 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // now register e of thread tl holds bin i = tl + e*T
 
             if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
-                double pr[16], pi[16];
+                // One component at a time, so only 16 partner values are live: the real parts give 0.5*(re[i] + re[n-i]) below
+                // n/2 and 0.5*(-re[n-i] + re[i]) above it, the imaginary parts 0.5*(im[i] - im[n-i]) and 0.5*(im[n-i] + im[i]).
+                // Above n/2 the two results land in swapped registers (the reference's real part sits in im[e]); only
+                // re*re + im*im is taken from here on, and that sum does not depend on the order.
+                double pp[16];
                 frame_sync<BLOCK_SYNC>();
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
                 frame_sync<BLOCK_SYNC>();
 #pragma unroll
-                for (int e = 0; e < 16; e++) pr[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = tl + e * T;
+                    const double orr = re[e];
+                    if (i == 0) {
+                        // bin 0 keeps its real part
+                    } else if (i == N / 2) {
+                        re[e] = 0.0;
+                    } else if (i < N / 2) {
+                        re[e] = 0.5 * (orr + pp[e]);
+                    } else {
+                        re[e] = 0.5 * (-pp[e] + orr);
+                    }
+                }
                 frame_sync<BLOCK_SYNC>();
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = im[e];
                 frame_sync<BLOCK_SYNC>();
 #pragma unroll
-                for (int e = 0; e < 16; e++) pi[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int i = tl + e * T;
-                    const double orr = re[e], oi = im[e];
-                    if (i == 0) {
-                        im[e] = 0.0;
-                    } else if (i == N / 2) {
-                        re[e] = 0.0;
+                    const double oi = im[e];
+                    if (i == 0 || i == N / 2) {
                         im[e] = 0.0;
                     } else if (i < N / 2) {
-                        re[e] = 0.5 * (orr + pr[e]);
-                        im[e] = 0.5 * (oi - pi[e]);
+                        im[e] = 0.5 * (oi - pp[e]);
                     } else {
-                        re[e] = 0.5 * (pi[e] + oi);
-                        im[e] = 0.5 * (-pr[e] + orr);
+                        im[e] = 0.5 * (pp[e] + oi);
                     }
                 }
             }
