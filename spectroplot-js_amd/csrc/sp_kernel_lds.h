@@ -302,14 +302,18 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
 // The raw words of the NEXT frame are requested right after the current frame has been decoded and are consumed one frame
 // later, so HBM latency is covered by a whole frame of butterflies; no other vector-memory load sits inside the frame loop
 // at n <= 1024 (twiddles and tables are in LDS), so nothing forces an early wait on them.
+// 3-byte samples are fetched as one unaligned dword; `back` (0 or 1) moves the load one byte down for a frame that ends with the
+// buffer, whose last dword would otherwise reach one byte past it (the decode shifts such words right by 8).
 template <int BYTES>
 __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start, int T, int sidx, uint32_t (&lo)[16],
-                                 uint32_t (&hi)[BYTES == 8 ? 16 : 1])
+                                 uint32_t (&hi)[BYTES == 8 ? 16 : 1], int back = 0)
 {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const uint8_t *p = base + (start + rev4(e) * T + sidx) * BYTES;
-        if constexpr (BYTES == 2) {
+        if constexpr (BYTES == 3) {
+            lo[e] = *(const uint32_t *)(p - back);
+        } else if constexpr (BYTES == 2) {
             lo[e] = *(const uint16_t *)p;
         } else if constexpr (BYTES == 4) {
             lo[e] = *(const uint32_t *)p;
@@ -325,12 +329,12 @@ __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start
 // Returns true if the frame may hold infinities or NaNs (float formats; integer formats never do).
 template <int FMT, int NHI>
 __device__ inline bool decode_frame(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI], const double (&win)[16], double (&re)[16],
-                                    double (&im)[16])
+                                    double (&im)[16], int shift = 0)
 {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         double vi, vq;
-        spfmt::decode_raw<FMT>(lo[e], hi[NHI == 16 ? e : 0], vi, vq);
+        spfmt::decode_raw<FMT>((FMT == SP_FMT_CU12 || FMT == SP_FMT_CS12) ? lo[e] >> shift : lo[e], hi[NHI == 16 ? e : 0], vi, vq);
         re[e] = win[e] * vi;                                                   // worker.js:73-74
         im[e] = win[e] * vq;
     }
@@ -355,7 +359,7 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
 }
 
 
-template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 4, 8) or 0 = no prefetch
+template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 3, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                          const int group_frames, const int groups)
 {
@@ -401,11 +405,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
     const int rounds = group_frames / FPB;
     uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
+    int raw_back = 0;   // 3-byte samples: 1 if the words now in raw_lo were fetched one byte low (frame ending with the buffer)
     auto request = [&](int xq) {
         if constexpr (PF) {
         const int xc = xq < a.width ? xq : a.width - 1;
         const int64_t st = frame_start(a.stride, xc);
-        issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi);
+        if constexpr (PFB == 3) raw_back = (st + N) * 3 + 1 > a.nbytes ? 1 : 0;
+        issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
         }
     };
     // the first frame's samples are requested before the tables: one HBM round trip for both
@@ -587,7 +593,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
-                if constexpr (PFB == 2) {
+                if constexpr (PFB == 3) {
+                    if (format == SP_FMT_CU12) nonfinite = decode_frame<SP_FMT_CU12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
+                    else nonfinite = decode_frame<SP_FMT_CS12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
+                } else if constexpr (PFB == 2) {
                     if (format == SP_FMT_CU8) nonfinite = decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
                     else nonfinite = decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
                 } else if constexpr (PFB == 4) {
@@ -883,14 +892,18 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
                            format, stage_tw, gf, groups);                                                                \
     }
 #define SP_LAUNCH_CH(L, C)                                                                                               \
-    if (prefetch == 8) SP_LAUNCH_V(L, C, 8) else if (prefetch == 4) SP_LAUNCH_V(L, C, 4) else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else SP_LAUNCH_V(L, C, 0)
+    if (prefetch == 8) SP_LAUNCH_V(L, C, 8) else if (prefetch == 4) SP_LAUNCH_V(L, C, 4) else if (prefetch == 3) SP_LAUNCH_V(L, C, 3)    \
+    else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else SP_LAUNCH_V(L, C, 0)
 #define SP_LAUNCH(L)                                                                                                     \
     case L:                                                                                                              \
         if (a.channel_mode) { SP_LAUNCH_CH(L, true) } else { SP_LAUNCH_CH(L, false) }                                    \
         break;
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
     // next-frame register prefetch: frames inside the buffer, 2-, 4- or 8-byte samples
-    const int prefetch = (a.in_bounds && (a.sample_width == 2 || a.sample_width == 4 || a.sample_width == 8)) ? a.sample_width : 0;
+    int prefetch = (a.in_bounds && (a.sample_width == 2 || a.sample_width == 3 || a.sample_width == 4 || a.sample_width == 8)) ? a.sample_width : 0;
+    // 3-byte samples are fetched as unaligned dwords, one byte low for a frame that ends with the buffer: that frame must not
+    // start at byte 0
+    if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
     switch (a.levels) {
         SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8) SP_LAUNCH(9) SP_LAUNCH(10) SP_LAUNCH(11) SP_LAUNCH(12) SP_LAUNCH(13)
     default: return SP_ERR_UNSUPPORTED;

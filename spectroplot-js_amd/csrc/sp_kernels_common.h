@@ -35,7 +35,7 @@ struct FrameArgs {
 };
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
-__device__ inline int32_t frame_start(double stride, int32_t x) { return spjs::to_int32(0.5 + stride * (double)x); }
+__host__ __device__ inline int32_t frame_start(double stride, int32_t x) { return spjs::to_int32(0.5 + stride * (double)x); }
 
 // Exact colour index from the edge table: number of edges 1..lut_len-1 that are <= abs2 (NaN -> 0).
 __device__ inline int32_t gray_exact(const double *edge, int32_t lut_len, double abs2)
