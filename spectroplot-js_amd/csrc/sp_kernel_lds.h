@@ -14,19 +14,23 @@
 //     imaginary parts, through the same padded buffer) and come back under the next window.  The arithmetic of each
 //     butterfly is exactly the reference's: 4 multiplies, 2 adds for the twiddle product, 4 adds/subtracts, each
 //     rounded on its own (compile with -ffp-contract=off).
-//   * Pass 0 (stages 1-4, window [0,4)) has compile-time twiddle indices (scalar loads); later passes read
-//     per-stage twiddle tables whose entries are consecutive across lanes.
+//   * Twiddles: per-stage tables, in LDS for stages <= 10 (lane-uniform broadcast reads in the first pass, consecutive
+//     across lanes later) and in L2 above; the reads of a pass go out as one batch ahead of its re-distribution.
+//     n = 512 / 1024 do their second re-distribution in registers (v_permlane16_swap / v_permlane32_swap).
 //   * Input: thread tl of a frame owns positions 16*tl + e, i.e. samples rev4(e)*T + rev(tl): every load instruction
-//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.
+//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.  2-, 3-, 4- and
+//     8-byte samples are requested one frame ahead into registers.
 //   * Epilogue: |X|^2 in f64 -> colour index and centi-bel bin by a v_log_f32 first guess corrected against exact
-//     edge tables in LDS (no f64 log per pixel) -> LDS histograms (clipped ends counted in registers) ->
-//     one byte per pixel into an LDS tile [frame][bin] -> after F frames the workgroup writes the tile out through
-//     the RGBA LUT as 16-byte stores: 128-byte row segments in spectrogram layout, whole rows in waterfall layout.
-//   * Per-frame min/max of |X|^2 go to HBM; the finish kernel turns them into gauges and the dBfs range.
+//     edge tables in LDS (no f64 log per pixel) -> LDS histograms (clipped colour indices counted per wave on the
+//     scalar unit, rare centi-bel ends on a slow path) -> one byte per pixel into an LDS tile [frame][bin]; frame
+//     extremes of |X|^2 by LDS integer atomics on the bit patterns.
+//   * After F frames the workgroup writes the tile out through the RGBA LUT as 16-byte stores (128-byte row segments
+//     in spectrogram layout, whole rows in waterfall layout), between the decode and the epilogue of the next
+//     group's first frame.  Histograms and the launch's extreme |X|^2 go to context accumulators at the end; the
+//     finish kernel (sp_kernel_scratch.h) turns per-frame extremes into gauges and moves the accumulators to the reply.
 #pragma once
 
 #include "sp_kernels_common.h"
-
 
 // Compile-time tunables (tools/build_variant.sh builds a library variant with other values; tools/ab_kernel.sh compares
 // variants on one GPU in one call).  The defaults are the measured best for config 2 on MI355X.
