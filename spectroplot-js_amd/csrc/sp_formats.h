@@ -180,7 +180,7 @@ SP_HD inline void sample_fast(const uint8_t *p, int64_t pos, double &vi, double 
     }
 }
 
-// Both components from the raw little-endian words of one sample that is already in registers (2-, 3-, 4- and 8-byte samples:
+// Both components from the raw little-endian words of one sample that is already in registers (1-, 2-, 3-, 4- and 8-byte samples:
 // lo = the first four bytes, hi = the next four).  Same arithmetic as sample_fast.
 template <int FMT>
 SP_HD inline void decode_raw(uint32_t lo, uint32_t hi, double &vi, double &vq)
@@ -198,6 +198,14 @@ SP_HD inline void decode_raw(uint32_t lo, uint32_t hi, double &vi, double &vq)
     } else if constexpr (FMT == SP_FMT_CS16) {
         vi = (double)(int16_t)(lo & 0xffff) * f.scale;
         vq = (double)(int16_t)(lo >> 16) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CU4) {
+        const int32_t b = lo & 0xff;
+        vi = ((double)(b >> 4) - f.bias) * f.scale;
+        vq = ((double)(b & 15) - f.bias) * f.scale;
+    } else if constexpr (FMT == SP_FMT_CS4) {
+        const int32_t b = lo & 0xff;
+        vi = (double)((int32_t)((uint32_t)(b & 0xf0) << 24) >> 28) * f.scale;
+        vq = (double)((int32_t)((uint32_t)b << 28) >> 28) * f.scale;
     } else if constexpr (FMT == SP_FMT_CU12 || FMT == SP_FMT_CS12) {
         const int32_t b0 = lo & 0xff, b1 = (lo >> 8) & 0xff, b2 = (lo >> 16) & 0xff;   // the sample's three bytes
         if constexpr (FMT == SP_FMT_CU12) {
@@ -214,7 +222,7 @@ SP_HD inline void decode_raw(uint32_t lo, uint32_t hi, double &vi, double &vq)
         vi = (double)(int32_t)lo * f.scale;
         vq = (double)(int32_t)hi * f.scale;
     } else {
-        static_assert(FMT == SP_FMT_CF32, "decode_raw covers the 2-, 3-, 4- and 8-byte sample formats");
+        static_assert(FMT == SP_FMT_CF32, "decode_raw covers the 1-, 2-, 3-, 4- and 8-byte sample formats");
         float a, b;
         memcpy(&a, &lo, 4);
         memcpy(&b, &hi, 4);

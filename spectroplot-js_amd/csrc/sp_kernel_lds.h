@@ -18,8 +18,8 @@
 //     across lanes later) and in L2 above; the reads of a pass go out as one batch ahead of its re-distribution.
 //     n = 512 / 1024 do their second re-distribution in registers (v_permlane16_swap / v_permlane32_swap).
 //   * Input: thread tl of a frame owns positions 16*tl + e, i.e. samples rev4(e)*T + rev(tl): every load instruction
-//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.  2-, 3-, 4- and
-//     8-byte samples are requested one frame ahead into registers.
+//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.  1-, 2-, 3-, 4-
+//     and 8-byte samples are requested one frame ahead into registers.
 //   * Epilogue: |X|^2 in f64 -> colour index and centi-bel bin by a v_log_f32 first guess corrected against exact
 //     edge tables in LDS (no f64 log per pixel) -> LDS histograms (clipped colour indices counted per wave on the
 //     scalar unit, rare centi-bel ends on a slow path) -> one byte per pixel into an LDS tile [frame][bin]; frame
@@ -317,6 +317,8 @@ __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start
         const uint8_t *p = base + (start + rev4(e) * T + sidx) * BYTES;
         if constexpr (BYTES == 3) {
             lo[e] = *(const uint32_t *)(p - back);
+        } else if constexpr (BYTES == 1) {
+            lo[e] = *p;
         } else if constexpr (BYTES == 2) {
             lo[e] = *(const uint16_t *)p;
         } else if constexpr (BYTES == 4) {
@@ -363,7 +365,7 @@ __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int t
 }
 
 
-template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (2, 3, 4, 8) or 0 = no prefetch
+template <int LOG2N, bool CH, int PFB>   // PFB: bytes per sample of the register-prefetch path (1, 2, 3, 4, 8) or 0 = no prefetch
 __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                          const int group_frames, const int groups)
 {
@@ -597,7 +599,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             // the frame this slot processes next
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
-                if constexpr (PFB == 3) {
+                if constexpr (PFB == 1) {
+                    if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS4, 1>(raw_lo, raw_hi, win, re, im);
+                } else if constexpr (PFB == 3) {
                     if (format == SP_FMT_CU12) nonfinite = decode_frame<SP_FMT_CU12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
                     else nonfinite = decode_frame<SP_FMT_CS12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
                 } else if constexpr (PFB == 2) {
@@ -897,14 +902,14 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     }
 #define SP_LAUNCH_CH(L, C)                                                                                               \
     if (prefetch == 8) SP_LAUNCH_V(L, C, 8) else if (prefetch == 4) SP_LAUNCH_V(L, C, 4) else if (prefetch == 3) SP_LAUNCH_V(L, C, 3)    \
-    else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else SP_LAUNCH_V(L, C, 0)
+    else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else if (prefetch == 1) SP_LAUNCH_V(L, C, 1) else SP_LAUNCH_V(L, C, 0)
 #define SP_LAUNCH(L)                                                                                                     \
     case L:                                                                                                              \
         if (a.channel_mode) { SP_LAUNCH_CH(L, true) } else { SP_LAUNCH_CH(L, false) }                                    \
         break;
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
     // next-frame register prefetch: frames inside the buffer, 2-, 4- or 8-byte samples
-    int prefetch = (a.in_bounds && (a.sample_width == 2 || a.sample_width == 3 || a.sample_width == 4 || a.sample_width == 8)) ? a.sample_width : 0;
+    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;   // 1, 2, 3, 4, 8 bytes per sample
     // 3-byte samples are fetched as unaligned dwords, one byte low for a frame that ends with the buffer: that frame must not
     // start at byte 0
     if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
