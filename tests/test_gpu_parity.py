@@ -439,3 +439,30 @@ def test_three_byte_samples_to_the_last_byte(pkg, ctx, fmt, n, frames, extra):
         want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width)
         got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width)
         _assert_same(got, want)
+
+
+def test_full_size_repeatable(pkg, ctx):
+    """Config 2 at full size, executed three times into separate buffers: every output byte identical between runs (a race
+    between waves, tiles or accumulators would show up as a difference)."""
+    n, S, fmt = 1024, 1 << 24, "CF32"
+    W = S // n
+    win, weight = pyoracle.window("blackmanHarris", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    d_in = ctx.alloc(S * 8)
+    ctx.synth_trinoise(d_in, fmt, 0, S, 0x5EED0001, 7321, 11, 0.5, 0.02)
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+    sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+    runs = []
+    for _ in range(3):
+        ptrs = [ctx.alloc(s) for s in sizes]
+        plan.execute(d_in, S * 8, W, *ptrs)
+        ctx.synchronize()
+        runs.append([ctx.download(p, s) for p, s in zip(ptrs, sizes)])
+        for p in ptrs:
+            ctx.free(p)
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert np.array_equal(a, b)
+    ctx.free(d_in)
+    plan.close()
