@@ -1,0 +1,54 @@
+'use strict'
+/**
+ * What the drop-in buys a Node caller: round-trip time of one worker message (postMessage -> onmessage, host buffers, PCIe
+ * both ways) through HipWorker versus the same message through the JavaScript restatement of the reference worker
+ * (oracle/js/worker_oracle.js, bit-identical to lib/worker.js) on this host.  Replies are compared on the way.
+ *   node tools/js_dropin_bench.js            (run on a machine with a HIP device)
+ */
+const path = require('path')
+const root = path.join(__dirname, '..')
+const O = require(path.join(root, 'oracle', 'js', 'worker_oracle.js'))
+const siggen = require(path.join(root, 'oracle', 'js', 'siggen.js'))
+const { HipWorker } = require(path.join(root, 'spectroplot-js_amd', 'js'))
+
+const GEN = { kind: 'trinoise', seed: 0x5EED0001, step: 7321, gshift: 11, amp: 0.5, namp: 0.02 }
+function message(format, S, n, windowName) {
+    const bytes = siggen.generate(format, GEN, S, 0)
+    const { window: windowc, weight } = O.makeWindow(windowName, n)
+    const cmap = []
+    for (let i = 0; i < 256; i++) cmap.push([i, 255 - i, (i * 3) & 255])
+    cmap[0] = [0, 0, 0]; cmap[255] = [255, 255, 255]
+    return { block_norm: 1.0 / weight, gain: 6, range: 30, cmap, n, windowc, width: S / n, offset: 0, buffer: bytes.buffer, format,
+        channelMode: false, waterfall: false }
+}
+function ask(worker, m) {
+    return new Promise((resolve, reject) => {
+        worker.onmessage = e => resolve(e.data)
+        worker.onerror = reject
+        worker.postMessage(m, [])
+    })
+}
+async function main() {
+    const worker = new HipWorker()
+    for (const [name, format, log2s, n, win] of [['config 1', 'CU8', 20, 512, 'hann'], ['config 2 / 4', 'CF32', 22, 1024, 'blackmanHarris'],
+        ['config 2', 'CF32', 24, 1024, 'blackmanHarris']]) {
+        const m = message(format, 2 ** log2s, n, win)
+        await ask(worker, m)                                   // warm-up: plan creation, first allocation
+        const reps = 5
+        let t0 = process.hrtime.bigint()
+        let reply
+        for (let i = 0; i < reps; i++) reply = await ask(worker, m)
+        const gpu_ms = Number(process.hrtime.bigint() - t0) / 1e6 / reps
+        let cpu_ms = null, same = null
+        if (log2s <= 22) {
+            O.render(m)
+            t0 = process.hrtime.bigint()
+            const ref = O.render(m)
+            cpu_ms = Number(process.hrtime.bigint() - t0) / 1e6
+            same = Buffer.compare(Buffer.from(ref.imageData.data.buffer), Buffer.from(reply.imageData.data.buffer)) === 0
+        }
+        console.log(`${name}: ${format} 2^${log2s} samples, n=${n}: HipWorker ${gpu_ms.toFixed(2)} ms per message` +
+            (cpu_ms ? `, JS worker ${cpu_ms.toFixed(0)} ms (x${(cpu_ms / gpu_ms).toFixed(0)}), images identical: ${same}` : ''))
+    }
+}
+main().catch(e => { console.error(e); process.exit(1) })
