@@ -21,20 +21,14 @@ const DEFAULT_OPTS = { dbfsWidth: 60, timeHeight: 20, rampTop: 10, rampWidth: 15
 
 /** The colour ramp image: row y shows LUT entry `len-1 - round(y*(len-1)/(height-1))`   (lib/spectroplot.js:646-660). */
 function colorRamp(cmap, rampWidth, rampHeight) {
-    const data = new Uint8ClampedArray(4 * rampWidth * rampHeight)
-    const color_max = cmap.length - 1
-    for (let y = 0; y < rampHeight; ++y) {
-        const idx = Math.round(y * color_max / (rampHeight - 1))
-        const color = cmap[color_max - idx]
-        for (let x = 0; x < rampWidth; ++x) {
-            const j = x * 4 + rampWidth * y * 4
-            data[j + 0] = color[0]
-            data[j + 1] = color[1]
-            data[j + 2] = color[2]
-            data[j + 3] = 255
-        }
+    const top = cmap.length - 1
+    const out = new Uint8ClampedArray(4 * rampWidth * rampHeight)
+    for (let row = 0; row < rampHeight; ++row) {
+        const rgb = cmap[top - Math.round(row * top / (rampHeight - 1))]
+        const base = 4 * rampWidth * row
+        for (let col = 0; col < rampWidth; ++col) out.set([rgb[0], rgb[1], rgb[2], 255], base + 4 * col)
     }
-    return { data, width: rampWidth, height: rampHeight }
+    return { data: out, width: rampWidth, height: rampHeight }
 }
 
 /**
@@ -43,24 +37,28 @@ function colorRamp(cmap, rampWidth, rampHeight) {
  */
 function rampMarkers(o) {
     const opts = Object.assign({}, DEFAULT_OPTS, o.opts), theme = Object.assign({}, DEFAULT_THEME, o.theme)
-    const gain = o.gain, dB_range = o.range, height = o.height
     const histWidth = o.histWidth === undefined ? opts.histWidth : o.histWidth
-    const calls = []
-    const font_y = 10
-    const rampLeft = 35, rampTop = opts.rampTop, rampHeight = height
-    const ramp = colorRamp(o.cmap, opts.rampWidth, rampHeight)
-    calls.push(['putImageData', rampLeft, rampTop, ramp.width, ramp.height, ramp])
-    const num_dbfs_markers = height / 50
-    let dbfs_markers_step = (gain + dB_range) / num_dbfs_markers
-    dbfs_markers_step = Math.round(dbfs_markers_step / 3) * 3
-    if (dbfs_markers_step < 1.0) dbfs_markers_step = 1.0
-    for (let d = gain; d < gain + dB_range; d += dbfs_markers_step) {
-        if (d >= gain + dB_range - dbfs_markers_step) d = gain + dB_range
-        const y = rampTop + rampHeight * (d - gain) / dB_range
-        calls.push(['fillRect', 30, y, 5, 1, theme.rampFill])
-        calls.push(['fillText', (-d).toFixed(0), 11, y + font_y / 2 - 1])
+    const lo = o.gain, span = o.range, hi = lo + span, rows = o.height
+    const ramp = colorRamp(o.cmap, opts.rampWidth, rows)
+    const calls = [['putImageData', 35, opts.rampTop, ramp.width, ramp.height, ramp]]
+    // about one tick per 50 px, in steps that are multiples of 3 dB (at least 1 dB); the last tick lands on the scale's end
+    let step = Math.round(hi / (rows / 50) / 3) * 3
+    if (step < 1.0) step = 1.0
+    const labelDrop = 10 / 2 - 1                                   // half the 10 px font, one pixel up
+    for (let level = lo; level < hi; level += step) {
+        if (level >= hi - step) level = hi
+        const y = opts.rampTop + rows * (level - lo) / span
+        calls.push(['fillRect', 30, y, 5, 1, theme.rampFill], ['fillText', (-level).toFixed(0), 11, y + labelDrop])
     }
-    return { canvas: { width: opts.dbfsWidth + histWidth, height: height + opts.timeHeight }, calls }
+    return { canvas: { width: opts.dbfsWidth + histWidth, height: rows + opts.timeHeight }, calls }
+}
+
+// one filled outline: from (left, top) down the rows, x = left + width * count / peak, closing at (left, top + rows)
+function outline(left, top, rows, xOf, fill, stroke, line) {
+    const path = [['beginPath'], ['moveTo', left, top]]
+    for (let row = 0; row < rows; ++row) path.push(['lineTo', left + xOf(row), top + row])
+    path.push(['lineTo', left, top + rows], ['fill', fill], ['stroke', stroke, line])
+    return path
 }
 
 /**
@@ -70,58 +68,34 @@ function rampMarkers(o) {
  */
 function histogramOutlines(o) {
     const opts = Object.assign({}, DEFAULT_OPTS, o.opts), theme = Object.assign({}, DEFAULT_THEME, o.theme)
-    const histWidth = o.histWidth === undefined ? opts.histWidth : o.histWidth
-    const histLeft = opts.histLeft
-    if (!histWidth) return []
-    const c_hist = o.c_hist, cB_hist = o.cB_hist
-    const color_max = o.cmapLength - 1
-    const rampHeight = o.height, rampTop = opts.rampTop
-    const calls = []
-    let c_hist_max = 0
-    calls.push(['beginPath'])
-    calls.push(['moveTo', histLeft, rampTop])
-    for (let i = 0; i <= color_max; ++i) if (c_hist[i] > c_hist_max) c_hist_max = c_hist[i]
-    for (let y = 0; y < rampHeight; ++y) {
-        const i = color_max - Math.round(y * color_max / (rampHeight - 1))
-        const h = histWidth * c_hist[i] / c_hist_max
-        calls.push(['lineTo', histLeft + h, rampTop + y])
-    }
-    calls.push(['lineTo', histLeft, rampTop + rampHeight])
-    calls.push(['fill', theme.histoFill])
-    calls.push(['stroke', theme.histoStroke, theme.histoLine])
-
-    const cB_hist_size = cB_hist.length
-    let cB_hist_max = 0
-    for (let i = 0; i < cB_hist_size; ++i) if (cB_hist[i] > cB_hist_max) cB_hist_max = cB_hist[i]
-    calls.push(['beginPath'])
-    calls.push(['moveTo', histLeft, rampTop])
-    for (let y = 0; y < rampHeight; ++y) {
-        const i = Math.round(y * (cB_hist_size - 1) / (rampHeight - 1))
-        const h = histWidth * cB_hist[i] / cB_hist_max
-        calls.push(['lineTo', histLeft + h, rampTop + y])
-    }
-    calls.push(['lineTo', histLeft, rampTop + rampHeight])
-    calls.push(['fill', theme.dbfsFill])
-    calls.push(['stroke', theme.dbfsStroke, theme.dbfsLine])
-    return calls
+    const wide = o.histWidth === undefined ? opts.histWidth : o.histWidth
+    if (!wide) return []
+    const rows = o.height, top = o.cmapLength - 1, last = o.cB_hist.length - 1
+    let colourPeak = 0, cbPeak = 0
+    for (let i = 0; i <= top; ++i) if (o.c_hist[i] > colourPeak) colourPeak = o.c_hist[i]
+    for (let i = 0; i <= last; ++i) if (o.cB_hist[i] > cbPeak) cbPeak = o.cB_hist[i]
+    const colour = outline(opts.histLeft, opts.rampTop, rows,
+        row => wide * o.c_hist[top - Math.round(row * top / (rows - 1))] / colourPeak, theme.histoFill, theme.histoStroke, theme.histoLine)
+    const centibel = outline(opts.histLeft, opts.rampTop, rows,
+        row => wide * o.cB_hist[Math.round(row * last / (rows - 1))] / cbPeak, theme.dbfsFill, theme.dbfsStroke, theme.dbfsLine)
+    return colour.concat(centibel)
 }
 
 /**
  * The gauge strips of one reply: per column a grey level `255 - gauge_max` and the two bars the reference fills
  * (lib/spectroplot.js:1246-1268): min/max bar from `~~(g_min*scale)` of height `~~((g_max-g_min)*scale)`, amplitude bar of
  * height `~~(g_amp*ampScale)`, at x = column + reply.offset.  NOT pinned by a reference vector: the block is inline in
- * processData's promise handler and cannot be run apart from the DOM-bound render; it is restated line by line.
+ * processData's promise handler and cannot be run apart from the DOM-bound render; it is restated from its arithmetic.
  */
 function gaugeColumns(reply, sliceWidth, minmaxHeight, ampHeight) {
-    const minmax = [], amp = []
-    const ampScale = ampHeight / 256, minmaxScale = minmaxHeight / 256
-    for (let x = 0; x < sliceWidth; x++) {
-        const g_min = reply.gauge_mins[x], g_max = reply.gauge_maxs[x], g_amp = reply.gauge_amps[x]
-        const style = `rgb(${255 - g_max},${255 - g_max},${255 - g_max})`
-        if (minmaxHeight) minmax.push(['fillRect', x + reply.offset, ~~(g_min * minmaxScale), 1, ~~((g_max - g_min) * minmaxScale), style])
-        if (ampHeight) amp.push(['fillRect', x + reply.offset, 0, 1, ~~(g_amp * ampScale), style])
+    const out = { minmax: [], amp: [] }
+    for (let col = 0; col < sliceWidth; col++) {
+        const lo = reply.gauge_mins[col], hi = reply.gauge_maxs[col]
+        const grey = 255 - hi, style = `rgb(${grey},${grey},${grey})`, x = col + reply.offset
+        if (minmaxHeight) out.minmax.push(['fillRect', x, ~~(lo * (minmaxHeight / 256)), 1, ~~((hi - lo) * (minmaxHeight / 256)), style])
+        if (ampHeight) out.amp.push(['fillRect', x, 0, 1, ~~(reply.gauge_amps[col] * (ampHeight / 256)), style])
     }
-    return { minmax, amp }
+    return out
 }
 
 module.exports = { colorRamp, rampMarkers, histogramOutlines, gaugeColumns, DEFAULT_THEME, DEFAULT_OPTS }
