@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "lds", "frames"], help="A/B runs: force a device kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,6 +119,8 @@ def main():
     win, weight = pkg.window(window, n)
     lut = load_cmap(cmap)
     plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, waterfall=args.waterfall)
+    if args.kernel != "auto":
+        plan.force_kernel(args.kernel)
 
     # operands resident in HBM
     d_in = torch.empty(S * sw, dtype=torch.uint8, device=dev)

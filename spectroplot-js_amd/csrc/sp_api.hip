@@ -16,6 +16,7 @@
 #include "../../include/spectroplot_hip.h"
 #include "sp_host.h"
 #include "sp_kernel_lds.h"
+#include "sp_kernel_frames.h"
 #include "sp_kernel_scratch.h"
 #include "sp_synth.h"
 
@@ -78,11 +79,14 @@ struct sp_plan {
     double block_norm_db = 0;
     float gray_a = 0, gray_b = 0, cb_a = 0, cb_b = 0;
     bool edges_in_f32 = false;      // every colour / centi-bel edge lies in [2^-100, 2^100]: the f32 first guess is enough
+    bool taper_finite = false;      // no +-inf / NaN in windowc: the (1, 0) butterflies may skip their products on integer samples
+    bool tw16_ok = false;           // the first-pass twiddle literals of k_frames equal this plan's table entries
+    sphost::Thresholds th{};        // f32 coefficients of both frame-loop kernels (edge vectors are released after the upload)
     DeviceBuffer tables;            // one allocation, carved below
     const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
     const uint32_t *d_lut = nullptr;
     const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
-    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds
+    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds_r16, 3 frames
 };
 
 namespace {
@@ -396,6 +400,14 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
     p->edges_in_f32 = true;
     for (int g = 1; g < L; g++) p->edges_in_f32 &= th.gray_edge[(size_t)g] >= 0x1p-100 && th.gray_edge[(size_t)g] <= 0x1p100;
     for (int j = 1; j <= SP_CB_HIST_SIZE; j++) p->edges_in_f32 &= th.cb_edge[(size_t)j] >= 0x1p-100 && th.cb_edge[(size_t)j] <= 0x1p100;
+    p->taper_finite = true;
+    for (int i = 0; i < n; i++) p->taper_finite &= std::isfinite(p->window[(size_t)i]);
+    p->tw16_ok = n >= 16;
+    for (int k = 0; k < 8 && p->tw16_ok; k++)
+        p->tw16_ok = ct[(size_t)k * (size_t)(n / 16)] == spk2::kTw16Host[k].c && st[(size_t)k * (size_t)(n / 16)] == spk2::kTw16Host[k].s;
+    p->th = th;
+    p->th.gray_edge.clear();
+    p->th.cb_edge.clear();
     std::vector<uint32_t> lut32((size_t)L);
     for (int i = 0; i < L; i++)
         lut32[(size_t)i] = (uint32_t)p->lut[3 * (size_t)i] | ((uint32_t)p->lut[3 * (size_t)i + 1] << 8)
@@ -463,28 +475,41 @@ extern "C" void sp_plan_destroy(sp_plan *plan)
     delete plan;
 }
 
+// Both LDS kernels skip the products of (1, 0) butterflies on integer samples, which is exact only with a finite taper; both
+// take their first index guess from f32, which needs every edge inside the f32 range.
 static bool plan_lds_capable(const sp_plan *plan)
 {
     return spk::lds_kernel_supports(plan->req.n) && plan->req.lut_len >= 2 && plan->req.lut_len <= spk::kLdsMaxLut
-           && plan->gray_b <= spk::kLdsMaxGrayB && plan->edges_in_f32;
+           && plan->gray_b <= spk::kLdsMaxGrayB && plan->edges_in_f32 && plan->taper_finite;
 }
 
-// 1 = scratch_radix2, 2 = lds_r16
+static bool plan_frames_capable(const sp_plan *plan)
+{
+    return plan_lds_capable(plan) && spk2::frames_kernel_supports(plan->req.n, spk2::frames_waves(plan->levels)) && plan->th.frames_ok && plan->tw16_ok;
+}
+
+// 1 = scratch_radix2, 2 = lds_r16, 3 = frames
 static int plan_kernel(const sp_plan *plan)
 {
     if (plan->force_kernel) return plan->force_kernel;
-    static const int env_kernel = getenv("SP_FORCE_KERNEL") ? atoi(getenv("SP_FORCE_KERNEL")) : 0;   // experiments only
+#ifdef SP_EXPERIMENT_KNOBS
+    static const int env_kernel = getenv("SP_FORCE_KERNEL") ? atoi(getenv("SP_FORCE_KERNEL")) : 0;
+    if (env_kernel == 3 && plan_frames_capable(plan)) return 3;
     if (env_kernel == 2 && plan_lds_capable(plan)) return 2;
     if (env_kernel == 1) return 1;
-    // The fused LDS kernel is the default; the scratch kernel covers every request the LDS kernel does not.
+#endif
+    // k_frames is the default, k_lds_r16 its predecessor (kept for A/B runs and as a second device path in the tests); the
+    // scratch kernel covers every request the LDS kernels do not.
+    if (plan_frames_capable(plan)) return 3;
     if (plan_lds_capable(plan)) return 2;
     return 1;
 }
 
 extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
 {
-    if (!plan || which < 0 || which > 2) return SP_ERR_INVALID_ARG;
-    if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "LDS kernel does not cover this request");
+    if (!plan || which < 0 || which > 3) return SP_ERR_INVALID_ARG;
+    if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "k_lds_r16 does not cover this request");
+    if (which == 3 && !plan_frames_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "k_frames does not cover this request");
     plan->force_kernel = which;
     return SP_OK;
 }
@@ -493,6 +518,7 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 {
     if (!plan) return "";
     switch (plan_kernel(plan)) {
+    case 3: return "frames";
     case 2: return "lds_r16";
     default: return "scratch_radix2";
     }
@@ -584,6 +610,16 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.gray_b = plan->gray_b;
     a.cb_a = plan->cb_a;
     a.cb_b = plan->cb_b;
+    a.g2_a = plan->th.g2_a;
+    a.g2_b = plan->th.g2_b;
+    a.g2_thr = plan->th.g2_thr;
+    a.g2_m = plan->th.g2_m;
+    a.c2_a = plan->th.c2_a;
+    a.c2_b = plan->th.c2_b;
+    a.c2_thr = plan->th.c2_thr;
+    a.c2_m = plan->th.c2_m;
+    a.c2_lo = plan->th.c2_lo;
+    a.c2_hi = plan->th.c2_hi;
     a.rgba = out->rgba;
     a.frame_min = (double *)ctx->frame_minmax.p;
     a.frame_max = a.frame_min + width;
@@ -596,8 +632,17 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
 
     const int which = plan_kernel(plan);
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (which == 2) {
-        rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, s);
+    if (which == 3) {
+#ifdef SP_STAMPS
+        // diagnostic build: per-wave phase clocks (tools/stamps.py reads them with sp_debug_read_stamps)
+        rc = ctx->scratch.reserve(4096 * 16 * 8 * sizeof(unsigned long long));
+        if (rc) return fail(ctx, rc, "stamps: out of device memory");
+        a.scratch = (double *)ctx->scratch.p;
+#endif
+        rc = spk2::launch_frames(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, ctx->device, s);
+        if (rc) return fail(ctx, rc, "k_frames launch rejected the configuration");
+    } else if (which == 2) {
+        rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, ctx->device, s);
         if (rc) return fail(ctx, rc, "LDS kernel launch rejected the configuration");
     } else {
         // scratch slabs: one per workgroup, capped at 256 MiB
@@ -648,6 +693,16 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     ctx->acc_dirty = false;
     return SP_OK;
 }
+
+#ifdef SP_STAMPS
+extern "C" int sp_debug_read_stamps(sp_context *ctx, unsigned long long *dst, size_t count)
+{
+    if (!ctx || !ctx->scratch.p) return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SP_HIP(ctx, hipMemcpy(dst, ctx->scratch.p, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return SP_OK;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------- merge of slice replies
 

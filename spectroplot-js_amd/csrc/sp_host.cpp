@@ -151,6 +151,37 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
     t.gray_b = (float)(per_db * c);
     t.cb_a = (float)((SP_CB_HIST_SIZE - 1) + 10.0 * pm.block_norm_db);
     t.cb_b = (float)(10.0 * c);
+
+    // ---- k_frames: floor(a + b*L) with L = v_log_f32((float)abs2), all in f32 -------------------------------------------------
+    // real-valued position of abs2:  colour 0.5 + color_max + per_db*dbfs,  level 999.5 + 10*rel_db  (dbfs = c*log2(abs2) + ...)
+    // error of the f32 evaluation, for abs2 in [2^-128, 2^128] (everything outside is clipped on both scales, see
+    // plan_frames_capable):  (float)abs2: 2^-24 relative = 2^-24 / ln 2 in L;  v_log_f32: <= 1 ulp of L (tests/test_gpu_parity.py
+    // sweeps it), counted as 2 ulp of 128 = 2^-16;  b rounded to f32: |b| * 2^-24 * 128;  a rounded to f32: (|a| + 1) * 2^-24;
+    // the fma's own rounding: half an ulp of the largest value that is not clamped (colour: lut_len + 64, level: 1024).
+    // The reference's own arithmetic places its steps within ~1e-12 of the real-valued positions (f64).  Safety factor 1.25.
+    auto margin = [&](double a, double b, double tmax) {
+        const double e_l = 0x1p-24 / 0.6931471805599453 + 0x1p-16;
+        const double ulp_t = std::ldexp(1.0, std::ilogb(tmax) - 23);
+        return 1.25 * (std::fabs(b) * e_l + std::fabs(b) * 0x1p-24 * 128.0 + (std::fabs(a) + 1.0) * 0x1p-24 + 0.5 * ulp_t) + 1e-7;
+    };
+    const double g_a = 0.5 + pm.color_max + per_db * (pm.block_norm_db + pm.gain), g_b = per_db * c;
+    const double c_a = (SP_CB_HIST_SIZE - 0.5) + 10.0 * pm.block_norm_db, c_b = 10.0 * c;
+    const double g_m = margin(g_a, g_b, (double)lut_len + 64.0), c_m = margin(c_a, c_b, 1024.0);
+    t.g2_a = (float)(g_a - g_m);
+    t.g2_b = (float)g_b;
+    t.g2_m = (float)g_m;
+    t.g2_thr = std::nextafterf((float)(1.0 - 2.0 * g_m), 0.0f);
+    t.c2_a = (float)(c_a - c_m);
+    t.c2_b = (float)c_b;
+    t.c2_m = (float)c_m;
+    t.c2_thr = std::nextafterf((float)(1.0 - 2.0 * c_m), 0.0f);
+    // level values below 0 or from 1000 - 2m up (the two-step bin 0 and the dropped keys, worker.js:105-106) always go to the
+    // edge tables: their clamp bounds have a fractional part past the threshold
+    t.c2_lo = -(float)(0.5 * c_m);
+    t.c2_hi = (float)((double)SP_CB_HIST_SIZE - c_m);
+    auto fractf_ = [](float v) { return v - std::floor(v); };
+    t.frames_ok = g_m < 0.125 && c_m < 0.125 && std::isfinite(t.g2_a) && std::isfinite(t.c2_a) && fractf_(t.c2_lo) >= t.c2_thr
+                  && fractf_(t.c2_hi) >= t.c2_thr && t.c2_hi < (float)SP_CB_HIST_SIZE;
     return t;
 }
 

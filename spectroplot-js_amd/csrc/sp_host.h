@@ -47,6 +47,13 @@ struct Thresholds {
     std::vector<double> cb_edge;     // [1001]
     // first-guess coefficients for the LDS kernel: floor(a + b*log2(abs2)) is the exact index or one below it
     float gray_a, gray_b, cb_a, cb_b;
+    // k_frames (sp_kernel_frames.h): t = a + b*log2((float)abs2) evaluated in f32 differs from the real-valued position of abs2
+    // on the index scale by less than the margin m (error model: sp_host.cpp).  a is stored lowered by m, so floor(t) is the
+    // exact index unless fract(t) >= thr = 1 - 2m; such lanes are decided against the edge tables.  frames_ok is false when a
+    // margin is too wide to be useful (extreme gain / range slopes).
+    float g2_a, g2_b, g2_thr, g2_m;
+    float c2_a, c2_b, c2_thr, c2_m, c2_lo, c2_hi;   // c2_lo / c2_hi: clamp bounds of the level value, both past the threshold
+    bool frames_ok;
 };
 Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len);
 

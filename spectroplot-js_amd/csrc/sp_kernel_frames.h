@@ -1,0 +1,729 @@
+// sp_kernel_frames.h — the frame-loop kernel for 64 <= n <= 8192 (gfx950), second generation.
+//
+// Same job and same butterfly graph as k_lds_r16 (sp_kernel_lds.h; lib/worker.js:68-137, lib/fft_nayuki.js:54-96), rebuilt
+// around what bounds it on MI355X.  tools/op_cost.hip (profiles/r02_op_cost.txt): an f64 multiply or add costs 4.4-4.7 issue
+// cycles per wave-instruction per SIMD whatever the occupancy, v_permlane32_swap 8, v_log_f32 8.5, conversions / floor / fract /
+// compares 4.4, 32-bit integer and f32 multiply-add 2.5; one wave alone reaches half of that, two waves reach it.  The reference's
+// unfused butterflies are 800 f64 wave-instructions per 1024-point frame, so the loop is bound by VALU issue, not by HBM, LDS
+// or latency, and every change here moves work off the VALU or removes it:
+//   * first pass (stages 1-4): its eight twiddles cos / sin(2 pi k / 16) are the same doubles for every n >= 16 (the table
+//     index k*n/16 is scaled by a power of two before the division by n), so they are literals: no LDS reads, no registers;
+//     the butterflies whose twiddle is (1, 0) skip their products when the frame is finite (integer formats always; float
+//     frames after one f32 multiply-add per raw word), the ones whose sine is exactly 1 skip two products always;
+//   * both re-distributions go through LDS (the register transpose with v_permlane swaps cost 64 x 8 cycles per frame);
+//   * epilogue: colour index and centi-bel level are floor(a + b*log2(|X|^2)) in f32; a lane is sent to the exact edge tables
+//     only if its f32 value lies within a proven error margin of an integer (a few lanes in a thousand), so the common path has
+//     no LDS read, no f64 compare and no data-dependent bank conflict; clipped colour indices land in lane-private histogram
+//     words through lane-dependent clamp bounds instead of compare / select / ballot sequences.
+// Everything else (input prefetch, exchange buffer, tile and write-out, per-frame extremes) follows k_lds_r16.
+#pragma once
+
+#include "sp_kernel_lds.h"
+
+namespace spk2 {
+
+using namespace spk;
+
+// cos / sin(2 pi k / 16), k = 0..7, as sphost::twiddles produces them for every n >= 16 (sp_api.hip checks it per plan).
+struct Tw16 {
+    double c, s;
+};
+__device__ constexpr Tw16 kTw16[8] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},
+    {0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bccp-1},
+    {0x1.87de2a6aea964p-2, 0x1.d906bcf328d46p-1},
+    {0x1.1a62633145c07p-54, 0x1.0000000000000p+0},
+    {-0x1.87de2a6aea962p-2, 0x1.d906bcf328d46p-1},
+    {-0x1.6a09e667f3bccp-1, 0x1.6a09e667f3bcdp-1},
+    {-0x1.d906bcf328d46p-1, 0x1.87de2a6aea965p-2},
+};
+inline constexpr Tw16 kTw16Host[8] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},
+    {0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bccp-1},
+    {0x1.87de2a6aea964p-2, 0x1.d906bcf328d46p-1},
+    {0x1.1a62633145c07p-54, 0x1.0000000000000p+0},
+    {-0x1.87de2a6aea962p-2, 0x1.d906bcf328d46p-1},
+    {-0x1.6a09e667f3bccp-1, 0x1.6a09e667f3bcdp-1},
+    {-0x1.d906bcf328d46p-1, 0x1.87de2a6aea965p-2},
+};
+
+constexpr int kClipWords = 64;        // lane-private histogram words on either side of the colour histogram
+constexpr int kCbTrashWords = 64;     // lane-private words behind the level histogram (dropped keys)
+constexpr int kMmSlotsMax = 4;
+
+__host__ __device__ inline constexpr int mm_slots(int n)
+{
+    return lds_mm_slots(n) < kMmSlotsMax ? lds_mm_slots(n) : kMmSlotsMax;
+}
+
+__host__ __device__ inline bool frames_kernel_supports(int n, int waves)
+{
+    if (!lds_kernel_supports(n)) return false;
+    const int threads = waves * 64, T = n / 16;
+    return T <= threads && threads % T == 0;
+}
+
+// frames per output group (tile height): a multiple of the frames per round and of 4 (the write-out handles frame quads)
+__host__ __device__ inline int group_frames_for(int n, int want, int threads)
+{
+    const int fpb = threads * 16 / n;
+    int unit = fpb;
+    while (unit % 4) unit *= 2;          // lcm(fpb, 4) for fpb in {1, 2, 3, 6, 12, ...}
+    int cap = 32768 / n;
+    if (cap > want) cap = want;
+    int f = cap / unit * unit;
+    if (f < unit) f = unit;
+    return f;
+}
+
+struct Layout {
+    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_chist, off_cbhist, off_win, total;
+    int chist_words, cbhist_words;
+};
+
+__host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds)
+{
+    Layout l;
+    const int fpb = threads * 16 / n;
+    int o = fpb * (n + n / 16) * 8;                              // exchange buffers
+    l.off_tw = o;     o += lds_tw_entries(n) * 16;
+    l.off_gedge = o;  o += edges_lds ? lut_len * 8 : 0;
+    l.off_cbedge = o; o += edges_lds ? (SP_CB_HIST_SIZE + 1) * 8 : 0;
+    o = (o + 15) & ~15;
+    l.off_mm = o;     o += group_frames * mm_slots(n) * 2 * 8;
+    l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
+    l.off_lut = o;    o += lut_len * 4;
+    l.chist_words = lut_len + 2 * kClipWords;
+    l.cbhist_words = SP_CB_HIST_SIZE + 1 + kCbTrashWords;
+    l.off_chist = o;  o += l.chist_words * 4;
+    l.off_cbhist = o; o += l.cbhist_words * 4;
+    o = (o + 7) & ~7;
+    l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;
+    l.total = (o + 15) & ~15;
+    return l;
+}
+
+// First register pass: stages 1-4 inside window [0, 4) with literal twiddles.
+template <bool TRIV>
+__device__ inline void fft_pass1(double (&re)[16], double (&im)[16])
+{
+#pragma unroll
+    for (int s = 1; s <= 4; s++) {
+        const int u = s - 1;
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0++) {
+            if (e0 & (1 << u)) continue;
+            const int e1 = e0 | (1 << u);
+            const int k = (e0 & ((1 << u) - 1)) << (4 - s);     // fft_nayuki.js:76-78: table index j * n / size, in units of n / 16
+            const double c = kTw16[k].c, sn = kTw16[k].s;
+            const double rl = re[e1], il = im[e1];
+            double tpre, tpim;                                   // fft_nayuki.js:80-81
+            if (TRIV && k == 0) {
+                // (1, 0): x*1 + y*0 == x bit for bit for finite x, y (only the sign of a zero can differ; nothing depends on it)
+                tpre = rl;
+                tpim = il;
+            } else if (k == 4) {
+                // sine exactly 1: y*1 == y for every y, NaN and infinities included
+                tpre = rl * c + il;
+                tpim = il * c - rl;
+            } else {
+                tpre = rl * c + il * sn;
+                tpim = il * c - rl * sn;
+            }
+            const double rj = re[e0], ij = im[e0];
+            re[e1] = rj - tpre;
+            im[e1] = ij - tpim;
+            re[e0] = rj + tpre;
+            im[e0] = ij + tpim;
+        }
+    }
+}
+
+// Does any of the raw f32 words of this wave's frames hold an infinity or a NaN?  x*0 is NaN exactly for those.
+template <int NHI>
+__device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI])
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        s = fmaf(__uint_as_float(lo[e]), 0.0f, s);
+        s = fmaf(__uint_as_float(hi[NHI == 16 ? e : 0]), 0.0f, s);
+    }
+    return __ballot(s != s) != 0ull;
+}
+
+// Diagnostic builds (-DSP_STAMPS): shader-clock sums per wave between points where the wave has no LDS / memory operation to wait
+// for anyway (s_memtime returns through lgkmcnt).  No stamp executes in the product build.
+#ifdef SP_STAMPS
+#define SP_PIN8(v, o) asm volatile("" : "+v"(v[o]), "+v"(v[o + 1]), "+v"(v[o + 2]), "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), "+v"(v[o + 7]));
+#define SP_STAMP(k)                                                   \
+    {                                                                 \
+        SP_PIN8(re, 0) SP_PIN8(re, 8) SP_PIN8(im, 0) SP_PIN8(im, 8)    \
+        unsigned long long now_;                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+        stamp_sum[k] += now_ - stamp_last;                            \
+        stamp_last = now_;                                            \
+    }
+#else
+#define SP_STAMP(k)
+#endif
+
+template <int LOG2N, bool CH, int PFB, int WAVES, bool EDGES_LDS>
+__global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
+                                                       const int group_frames, const int groups)
+{
+    constexpr int kThreads = WAVES * 64;
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / 16;                       // threads per frame
+    constexpr int FPB = kThreads / T;               // frames per round
+    constexpr bool BLOCK_SYNC = T > 64;
+    constexpr int NPASS = (LOG2N + 3) / 4;
+#ifndef SP_X_STAGED
+#define SP_X_STAGED 0
+#endif
+#ifndef SP_X_LATEPF
+#define SP_X_LATEPF 0
+#endif
+    constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED;  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
+    // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
+    // requested when it starts and the other waves of the SIMD cover the latency
+    constexpr bool LATE_PF = WAVES > 8 || SP_X_LATEPF;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Layout lay = layout(N, a.lut_len, group_frames, kThreads, EDGES_LDS);
+    double *s_xch = (double *)smem;
+    double2 *s_tw = (double2 *)(smem + lay.off_tw);
+    const double *edge_g = EDGES_LDS ? (const double *)(smem + lay.off_gedge) : a.gray_edge;
+    const double *edge_cb = EDGES_LDS ? (const double *)(smem + lay.off_cbedge) : a.cb_edge;
+    unsigned long long *s_mm = (unsigned long long *)(smem + lay.off_mm);
+    unsigned char *s_tile = smem + lay.off_tile;
+    unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
+    unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);      // word w counts colour index w - kClipWords
+    unsigned int *s_cbhist = (unsigned int *)(smem + lay.off_cbhist);    // word l counts level l (bin 999 - l); words > 1000: dropped keys
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int fs = tid / T;                         // frame slot within a round
+    const int tl = tid % T;                         // thread within the frame
+    double *xbuf = s_xch + fs * (N + N / 16);
+    const int tile_pitch = N + kTilePad;
+    const int cmax = a.lut_len - 1;
+
+    // groups are dealt so that workgroups sharing an XCD (blockIdx % 8) own neighbouring groups
+    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int chunk = (groups + 7) >> 3;
+    const int g_end = min(groups, (xcd + 1) * chunk);
+
+    constexpr bool PF = PFB != 0;
+    const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    const int rounds = group_frames / FPB;
+    uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
+    int raw_back = 0;
+    auto request = [&](int xq) {
+        if constexpr (PF) {
+            const int xc = xq < a.width ? xq : a.width - 1;
+            const int64_t st = frame_start(a.stride, xc);
+            if constexpr (PFB == 3) raw_back = (st + N) * 3 + 1 > a.nbytes ? 1 : 0;
+            issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
+        }
+    };
+    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
+
+    {
+        // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
+        constexpr int NTW = lds_tw_entries(N);
+        constexpr int TWK = (NTW + kThreads - 1) / kThreads;
+        double2 tw_r[TWK > 0 ? TWK : 1];
+#pragma unroll
+        for (int k = 0; k < TWK; k++) {
+            const int i = tid + k * kThreads;
+            tw_r[k] = i < NTW ? stage_tw[i] : make_double2(0.0, 0.0);
+        }
+        const unsigned int lut_r = tid < a.lut_len ? a.lut_rgba[tid] : 0u;       // lut_len <= 256 < kThreads
+        double ge_r = 0.0, cb_r[(SP_CB_HIST_SIZE + kThreads) / kThreads];
+        if constexpr (EDGES_LDS) {
+            ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;
+#pragma unroll
+            for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
+                const int i = tid + k * kThreads;
+                cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TWK; k++) {
+            const int i = tid + k * kThreads;
+            if (i < NTW) s_tw[i] = tw_r[k];
+        }
+        if (tid < a.lut_len) s_lut[tid] = lut_r;
+        if constexpr (EDGES_LDS) {
+            if (tid < a.lut_len) ((double *)(smem + lay.off_gedge))[tid] = ge_r;
+#pragma unroll
+            for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
+                const int i = tid + k * kThreads;
+                if (i <= SP_CB_HIST_SIZE) ((double *)(smem + lay.off_cbedge))[i] = cb_r[k];
+            }
+        }
+        for (int i = tid; i < lay.chist_words; i += kThreads) s_chist[i] = 0;
+        for (int i = tid; i < lay.cbhist_words; i += kThreads) s_cbhist[i] = 0;
+    }
+
+    constexpr bool WIN_LDS = lds_win_in_lds(N);
+    double *s_win = (double *)(smem + lay.off_win);
+    const double *const wbase = s_win + (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    double win_reg[WIN_LDS ? 1 : 16];
+    if constexpr (WIN_LDS) {
+        for (int i = tid; i < N; i += kThreads) s_win[i] = a.window[i];
+    } else {
+        const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+#pragma unroll
+        for (int e = 0; e < 16; e++) win_reg[e] = a.window[rev4(e) * T + sidx];
+    }
+    constexpr int MMS = mm_slots(N);
+    for (int i = tid; i < group_frames * MMS; i += kThreads) {
+        s_mm[2 * i] = 0x7ff0000000000000ull;
+        s_mm[2 * i + 1] = 0ull;
+    }
+    lds_barrier();
+
+    const spfmt::View view{a.bytes, a.nbytes, a.nelem};
+    uint32_t pf_word = 0;
+    // epilogue constants (sp_host.cpp build_thresholds): t = a + b*log2(|X|^2), already lowered by the margin
+    const float g_a = a.g2_a, g_b = a.g2_b, g_thr = a.g2_thr, g_m = a.g2_m;
+    const float c_a = a.c2_a, c_b = a.c2_b, c_thr = a.c2_thr, c_m = a.c2_m, c_lo = a.c2_lo, c_hi = a.c2_hi;
+    // lane-dependent clamp bounds of the colour value: a clipped pixel of lane l counts in word -(l+1) or cmax+1+l
+    const float g_lo = -0.5f - (float)lane, g_hi = (float)cmax + 1.5f + (float)lane;
+    unsigned int *const chist0 = s_chist + kClipWords;
+
+    unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
+    auto drain = [&](const int x0, const int part, const int nparts) {
+        if (part == 0 && tid < group_frames) {
+            if (x0 + tid < a.width) {
+                unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
+#pragma unroll
+                for (int k = 0; k < MMS; k++) {
+                    const ulonglong2 v = *(const ulonglong2 *)(s_mm + 2 * (tid * MMS + k));
+                    bmn = v.x < bmn ? v.x : bmn;
+                    bmx = v.y > bmx ? v.y : bmx;
+                }
+                a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
+                a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
+                blk_mn = bmn < blk_mn ? bmn : blk_mn;
+                blk_mx = bmx > blk_mx ? bmx : blk_mx;
+            }
+#pragma unroll
+            for (int k = 0; k < MMS; k++)
+                *(ulonglong2 *)(s_mm + 2 * (tid * MMS + k)) = make_ulonglong2(0x7ff0000000000000ull, 0ull);
+        }
+        if (a.rgba) {
+            if (!a.waterfall) {
+                // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
+                // a thread owns 4 consecutive bins x 4 consecutive frames; the threads of a row cover one contiguous run
+                const int quads = group_frames / 4;
+                const int items = (N / 4) * quads;
+                for (int it0 = tid + part * 2 * kThreads; it0 < items; it0 += nparts * 2 * kThreads) {
+                    uint32_t gb[2][4];
+                    int i0v[2], xav[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int it = it0 + u * kThreads;
+                        const int itc = it < items ? it : it0;
+                        const int fq = itc % quads, bq = itc / quads;
+                        i0v[u] = bq * 4;
+                        xav[u] = it < items ? x0 + fq * 4 : a.width;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
+                    }
+                    uint32_t px[2][4][4];
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int xa = xav[u];
+                        if (xa >= a.width) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int i = i0v[u] + j;
+                            const int y = (N / 2 - i) & (N - 1);
+                            uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                                *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
+                            }
+                        }
+                    }
+                }
+            } else {
+                // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
+                const int items = group_frames * (N / 4);
+                for (int it = tid + part * kThreads; it < items; it += nparts * kThreads) {
+                    const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
+                    const int xa = x0 + f;
+                    if (xa >= a.width) continue;
+                    const unsigned char *row = s_tile + f * tile_pitch;
+                    uint32_t px[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) px[k] = s_lut[row[(c4 + k + N / 2 + 1) & (N - 1)]];
+                    uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
+                    *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
+                }
+            }
+        }
+    };
+    int drain_x0 = -1;
+#ifdef SP_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
+    const unsigned long long stamp_begin = stamp_last;
+#endif
+    for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
+        const int x0 = g * group_frames;
+        for (int r = 0; r < rounds; r++) {
+#ifdef SP_X_STAGGER
+            // experiment: the second wave of every SIMD starts each group late, so that the two are in different phases
+            if (r == 0 && (tid >> 8) == 1)
+                for (int q = 0; q < SP_X_STAGGER; q++) __builtin_amdgcn_s_sleep(32);
+#endif
+            const int fr = r * FPB + fs;
+            const int xr = x0 + fr;
+            const bool live = xr < a.width;
+            const int x = live ? xr : a.width - 1;
+            const int64_t start = frame_start(a.stride, x);
+
+            double re[16], im[16];
+            double win[16];
+            bool nonfinite = true;   // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
+            const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
+            if constexpr (PF && LATE_PF) request(xr);
+            if constexpr (PF) {
+                if constexpr (PFB == 1) {
+                    if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS4, 1>(raw_lo, raw_hi, win, re, im);
+                } else if constexpr (PFB == 3) {
+                    if (format == SP_FMT_CU12) nonfinite = decode_frame<SP_FMT_CU12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
+                    else nonfinite = decode_frame<SP_FMT_CS12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
+                } else if constexpr (PFB == 2) {
+                    if (format == SP_FMT_CU8) nonfinite = decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
+                } else if constexpr (PFB == 4) {
+                    if (format == SP_FMT_CU16) nonfinite = decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im);
+                    else nonfinite = decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im);
+                } else {
+                    if (format == SP_FMT_CU32) nonfinite = decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im);
+                    else if (format == SP_FMT_CS32) nonfinite = decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im);
+                    else {
+                        decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im);
+                        nonfinite = raw_f32_nonfinite<16>(raw_lo, raw_hi);
+                    }
+                }
+                if (!LATE_PF && xn >= 0) request(xn);           // in flight during this frame's butterflies
+            } else {
+                asm volatile("" ::"v"(pf_word));
+                if (a.in_bounds && xn >= 0 && xn < a.width) {
+                    const int lines = (N * a.sample_width + 127) >> 7;
+                    const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
+                    for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
+                }
+                switch (format) {
+#define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im); break;
+                    SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CU8) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12)
+                    SP_CASE(SP_FMT_CS12) SP_CASE(SP_FMT_CU16) SP_CASE(SP_FMT_CS16) SP_CASE(SP_FMT_CU32) SP_CASE(SP_FMT_CS32)
+                    SP_CASE(SP_FMT_CU64) SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32)
+#undef SP_CASE
+                default: load_frame<SP_FMT_CF64>(a, view, start, tl, T, LOG2N, win, re, im); break;
+                }
+            }
+
+            SP_STAMP(0)   // loop head, taper reads, wait for the samples, decode
+            unsigned tw_off = 0;
+            asm volatile("" : "+s"(tw_off));
+            const double2 *tw = stage_tw + tw_off;
+            if (SP_DRAIN_PARTS > 1 && drain_x0 >= 0) {
+                lds_barrier();
+                drain(drain_x0, 0, SP_DRAIN_PARTS);
+            }
+            // ---- first pass: literal twiddles ------------------------------------------------------------------------------
+            if constexpr (PFB == 0) {
+                fft_pass1<false>(re, im);            // frames may leave the buffer (NaN samples), 16-byte formats
+            } else if constexpr (PFB == 8) {
+                if (nonfinite) fft_pass1<false>(re, im);
+                else fft_pass1<true>(re, im);
+            } else {
+                fft_pass1<true>(re, im);             // integer samples times a finite taper (sp_api.hip: plan_frames_capable)
+            }
+            if (SP_DRAIN_PARTS >= 3 && drain_x0 >= 0) drain(drain_x0, 1, SP_DRAIN_PARTS);
+            if constexpr (NPASS >= 2) {
+                constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
+                constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
+                double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
+                PassTw<WS1, 5, STAGED ? 4 : E1> tw1;
+                if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
+                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
+                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                SP_STAMP(1)   // (first write-out slice,) first pass, first exchange
+                if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
+                else fft_pass<WS1, 5, E1>(re, im, tw1);
+                if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
+                if constexpr (NPASS >= 3) {
+                    constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
+                    constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
+                    double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
+                    PassTw<WS2, 9, STAGED ? 8 : E2> tw2;
+                    if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
+                    exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
+                    exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                    SP_STAMP(2)   // second pass, second exchange
+                    if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
+                    else fft_pass<WS2, 9, E2>(re, im, tw2);
+                    SP_STAMP(3)   // third pass
+                    if constexpr (NPASS >= 4) {
+                        constexpr int WS3 = LOG2N - 4;
+                        double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
+                        PassTw<WS3, 13, LOG2N> tw3;
+                        load_pass_tw(tw3, tl, s_tw, tw);
+                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
+                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
+                        fft_pass<WS3, 13, LOG2N>(re, im, tw3);
+                    }
+                }
+            }
+            // now register e of thread tl holds bin i = tl + e*T
+
+            if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS (as k_lds_r16)
+                double pp[16];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = tl + e * T;
+                    const double orr = re[e];
+                    if (i == 0) {
+                    } else if (i == N / 2) {
+                        re[e] = 0.0;
+                    } else if (i < N / 2) {
+                        re[e] = 0.5 * (orr + pp[e]);
+                    } else {
+                        re[e] = 0.5 * (-pp[e] + orr);
+                    }
+                }
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = im[e];
+                frame_sync<BLOCK_SYNC>();
+#pragma unroll
+                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = tl + e * T;
+                    const double oi = im[e];
+                    if (i == 0 || i == N / 2) {
+                        im[e] = 0.0;
+                    } else if (i < N / 2) {
+                        im[e] = 0.5 * (oi - pp[e]);
+                    } else {
+                        im[e] = 0.5 * (pp[e] + oi);
+                    }
+                }
+            }
+
+            if (drain_x0 >= 0) {
+                if (SP_DRAIN_PARTS == 1) lds_barrier();
+                drain(drain_x0, SP_DRAIN_PARTS - 1, SP_DRAIN_PARTS);
+                lds_barrier();
+                drain_x0 = -1;
+            }
+            SP_STAMP(4)   // last write-out slice and its barrier
+            // ---- |X|^2 -> colour index, centi-bel level ---------------------------------------------------------------------
+            // t = a + b*log2((float)|X|^2) in f32 is within the margin m of the real-valued position of |X|^2 on the index
+            // scale (sp_host.cpp); a and the clamp bounds are lowered by m, so floor(t) is exact unless fract(t) >= 1 - 2m.
+            // Lanes past that threshold (and centi-bel values at or beyond the ends of the scale, +-inf and NaN among them, whose
+            // clamp bounds lie past it by construction) take the exact edge compare.
+            double mn = spjs::inf(), mx = 0.0;
+            unsigned char *trow = s_tile + fr * tile_pitch;
+#ifdef SP_ABL_NOEPI
+            asm volatile("" ::"v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(re[4]), "v"(re[5]), "v"(re[6]), "v"(re[7]), "v"(re[8]), "v"(re[9]), "v"(re[10]), "v"(re[11]), "v"(re[12]), "v"(re[13]), "v"(re[14]), "v"(re[15]));
+            asm volatile("" ::"v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(im[4]), "v"(im[5]), "v"(im[6]), "v"(im[7]), "v"(im[8]), "v"(im[9]), "v"(im[10]), "v"(im[11]), "v"(im[12]), "v"(im[13]), "v"(im[14]), "v"(im[15]));
+            if (false) {
+#else
+            if (live) {
+#endif
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const double abs2 = re[e] * re[e] + im[e] * im[e];                 // worker.js:92
+                    mn = min_nn(mn, abs2);
+                    mx = max_nn(mx, abs2);
+                    const float l2 = __log2f((float)abs2);
+                    const float tg = __builtin_amdgcn_fmed3f(fmaf(g_b, l2, g_a), g_lo, g_hi);
+                    const float tc = __builtin_amdgcn_fmed3f(fmaf(c_b, l2, c_a), c_lo, c_hi);
+                    int gi = floor_to_int(tg);                                         // colour index, or a lane-private clip word
+                    int lv = floor_to_int(tc);                                         // level = 999 - centi-bel bin
+                    const bool risky = !(__builtin_amdgcn_fractf(tg) < g_thr) || !(__builtin_amdgcn_fractf(tc) < c_thr);
+                    if (__builtin_expect(__ballot(risky) != 0ull, 0)) {
+                        if (risky) {
+                            // nearest edge on either scale, then one exact comparison each (edges: sp_host.h Thresholds)
+                            int rg = (int)rintf(tg + g_m);
+                            rg = rg < 1 ? 1 : (rg > cmax ? cmax : rg);
+                            int rc = (int)rintf(tc + c_m);
+                            rc = rc < 1 ? 1 : (rc > SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE : rc);
+                            const double eg = edge_g[rg], ec = edge_cb[rc];
+                            gi = abs2 >= eg ? rg : rg - 1;                             // NaN: every comparison false -> index 0 below
+                            lv = abs2 >= ec ? rc : rc - 1;
+                            if (!(abs2 == abs2)) gi = 0;
+                            // -inf / +inf / NaN dB: ToInt32 gives key 0, i.e. bin 0 = level 999                     worker.js:105
+                            if (!(abs2 > 0.0) || abs2 == spjs::inf()) lv = SP_CB_HIST_SIZE - 1;
+                            if (lv == SP_CB_HIST_SIZE) lv = SP_CB_HIST_SIZE + 1 + lane;    // negative key: dropped
+                        }
+                    }
+#ifndef SP_ABL_NOTILE
+                    trow[tl + e * T] = (unsigned char)min(max(gi, 0), cmax);
+#endif
+#ifndef SP_ABL_NOHIST
+                    atomicAdd(&chist0[gi], 1u);
+                    atomicAdd(&s_cbhist[lv], 1u);
+#else
+                    asm volatile("" ::"v"(gi), "v"(lv));
+#endif
+                }
+                unsigned long long *slot = s_mm + 2 * (fr * MMS + (tl & (MMS - 1)));
+                atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
+                atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
+            }
+            SP_STAMP(5)   // epilogue
+        }
+        drain_x0 = x0;
+    }
+
+#ifdef SP_STAMPS
+    {
+        const unsigned long long loop_end = clock64();
+        if (lane == 0 && a.scratch) {
+            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 8;
+            for (int k = 0; k < 6; k++) dst[k] = stamp_sum[k];
+            dst[6] = loop_end - stamp_begin;
+            dst[7] = stamp_begin;
+        }
+    }
+#endif
+    // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
+    lds_barrier();
+    for (int i = tid; i < a.lut_len; i += kThreads) {
+        unsigned int v = chist0[i];
+        if (i == 0)
+            for (int k = 1; k <= kClipWords; k++) v += chist0[-k];
+        if (i == cmax)
+            for (int k = 1; k <= kClipWords; k++) v += chist0[cmax + k];
+        if (v) atomicAdd(&a.c_hist[i], (unsigned long long)v);
+    }
+    for (int i = tid; i < SP_CB_HIST_SIZE; i += kThreads) {
+        const unsigned int v = s_cbhist[i];
+        if (v) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)v);
+    }
+    if (drain_x0 >= 0) {
+        drain(drain_x0, 0, 1);
+        lds_barrier();
+    }
+    if (tid < group_frames) {
+        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
+        if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
+    }
+    lds_barrier();
+    if (tid == 0) {
+        if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
+        if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
+    }
+}
+
+// Waves per workgroup (one workgroup per CU): 8 = two per SIMD with the edge tables in LDS; 12 = three per SIMD (<= 168 VGPRs,
+// edge tables read from L2 by the rare lanes that need them, 24-frame groups) for the sizes whose frames fit a wave.
+#ifndef SP_FRAMES_WAVES
+#define SP_FRAMES_WAVES 8
+#endif
+#ifndef SP_X_EDGES_GLOBAL
+#define SP_X_EDGES_GLOBAL 0
+#endif
+__host__ __device__ inline constexpr int frames_waves(int log2n) { return log2n <= 10 ? SP_FRAMES_WAVES : 8; }
+
+// Per-n launchers, one translation unit each (sp_inst_frames.hip compiled once per LOG2N).
+template <int L>
+int launch_frames_n(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int prefetch,
+                    int device, hipStream_t stream);
+#define SP_DECL(L)                                                                                                              \
+    template <>                                                                                                                 \
+    int launch_frames_n<L>(const FrameArgs &, int, const double2 *, int, int, int, int, int, int, hipStream_t);
+SP_DECL(6) SP_DECL(7) SP_DECL(8) SP_DECL(9) SP_DECL(10) SP_DECL(11) SP_DECL(12) SP_DECL(13)
+#undef SP_DECL
+
+#ifdef SP_INST_FRAMES_LOG2N
+// per-device, per-variant opt-in to the full LDS (function attributes belong to the device's code object)
+template <int L, bool C, int P, int W, bool E>
+inline int launch_variant(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int device,
+                          hipStream_t stream)
+{
+    static bool attr_set[kMaxDevices] = {};
+    if (device < 0 || device >= kMaxDevices || !attr_set[device]) {
+        if (hipFuncSetAttribute((const void *)k_frames<L, C, P, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SP_ERR_HIP;
+        if (device >= 0 && device < kMaxDevices) attr_set[device] = true;
+    }
+    hipLaunchKernelGGL((k_frames<L, C, P, W, E>), dim3((unsigned)grid), dim3(W * 64), (size_t)lds_bytes, stream, a, format, stage_tw, gf,
+                       groups);
+    return SP_OK;
+}
+
+template <>
+int launch_frames_n<SP_INST_FRAMES_LOG2N>(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups,
+                                   int prefetch, int device, hipStream_t stream)
+{
+    constexpr int L = SP_INST_FRAMES_LOG2N;
+#define SP_V(C, P) return launch_variant<L, C, P, frames_waves(L), frames_waves(L) == 8 && !SP_X_EDGES_GLOBAL>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
+#define SP_CH(C)                                                                                              \
+    switch (prefetch) {                                                                                       \
+    case 8: SP_V(C, 8) case 4: SP_V(C, 4) case 3: SP_V(C, 3) case 2: SP_V(C, 2) case 1: SP_V(C, 1) default: SP_V(C, 0) \
+    }
+    if (a.channel_mode) { SP_CH(true) } else { SP_CH(false) }
+#undef SP_V
+#undef SP_CH
+}
+#endif
+
+// Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
+inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, int device, hipStream_t stream)
+{
+    const int waves = frames_waves(a.levels);
+    if (!frames_kernel_supports(a.n, waves) || a.lut_len > kLdsMaxLut || a.lut_len < 2) return SP_ERR_UNSUPPORTED;
+    const int n = a.n;
+#ifndef SP_X_WANT
+#define SP_X_WANT 32
+#endif
+    int want = SP_X_WANT;
+    while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
+    const int gf = group_frames_for(n, want, waves * 64);
+    const int groups = (a.width + gf - 1) / gf;
+    const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL);
+    if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
+    int grid = groups < cu_count ? groups : cu_count;
+    grid = (grid + 7) & ~7;
+    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;
+    if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
+    switch (a.levels) {
+#define SP_L(L) case L: return launch_frames_n<L>(a, format, stage_tw, grid, lay.total, gf, groups, prefetch, device, stream);
+        SP_L(6) SP_L(7) SP_L(8) SP_L(9) SP_L(10) SP_L(11) SP_L(12) SP_L(13)
+#undef SP_L
+    default: return SP_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace spk2

@@ -178,6 +178,10 @@ __device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw
             const double2 w = t.w[base + (e0 & ((1 << u) - 1))];
             const double c = w.x, sn = w.y;
             const double rl = re[e1], il = im[e1];
+#ifdef SP_ABL_NOBF
+            asm volatile("" ::"v"(c), "v"(sn));
+            continue;
+#endif
             const bool unit = TRIV && WS == 0 && (e0 & ((1 << u) - 1)) == 0;   // compile-time after unrolling
             const double tpre = unit ? rl : rl * c + il * sn;          // fft_nayuki.js:80
             const double tpim = unit ? il : il * c - rl * sn;          // fft_nayuki.js:81  (-rl*sn + il*c)
@@ -217,6 +221,9 @@ __device__ inline void frame_sync()
 template <int WS_FROM, int WS_TO, bool BLOCK_SYNC>
 __device__ inline void exchange(double (&v)[16], double *from, const double *to)   // from / to alias: no __restrict__
 {
+#ifdef SP_ABL_NOEXCH
+    return;
+#endif
     frame_sync<BLOCK_SYNC>();   // previous readers are done with the buffer
 #pragma unroll
     for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
@@ -872,55 +879,78 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     }
 }
 
+// Per-n launchers: each lives in its own translation unit (sp_inst_lds.hip compiled once per LOG2N) so that the 96 variants build
+// in parallel.  `device` indexes the per-device record of the LDS opt-in (function attributes belong to a device's code object).
+constexpr int kMaxDevices = 64;
+template <int L>
+int launch_lds_n(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int prefetch, int device,
+                 hipStream_t stream);
+#define SP_DECL(L)                                                                                                              \
+    template <>                                                                                                                 \
+    int launch_lds_n<L>(const FrameArgs &, int, const double2 *, int, int, int, int, int, int, hipStream_t);
+SP_DECL(6) SP_DECL(7) SP_DECL(8) SP_DECL(9) SP_DECL(10) SP_DECL(11) SP_DECL(12) SP_DECL(13)
+#undef SP_DECL
+
+#ifdef SP_INST_LDS_LOG2N
+template <int L, bool C, int P>
+inline int launch_lds_variant(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int device,
+                              hipStream_t stream)
+{
+    static bool attr_set[kMaxDevices] = {};
+    if (device < 0 || device >= kMaxDevices || !attr_set[device]) {
+        if (hipFuncSetAttribute((const void *)k_lds_r16<L, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SP_ERR_HIP;
+        if (device >= 0 && device < kMaxDevices) attr_set[device] = true;
+    }
+    hipLaunchKernelGGL((k_lds_r16<L, C, P>), dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lds_bytes, stream, a, format, stage_tw, gf, groups);
+    return SP_OK;
+}
+
+template <>
+int launch_lds_n<SP_INST_LDS_LOG2N>(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int prefetch,
+                                int device, hipStream_t stream)
+{
+    constexpr int L = SP_INST_LDS_LOG2N;
+#define SP_V(C, P) return launch_lds_variant<L, C, P>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
+#define SP_CH(C)                                                                                              \
+    switch (prefetch) {                                                                                       \
+    case 8: SP_V(C, 8) case 4: SP_V(C, 4) case 3: SP_V(C, 3) case 2: SP_V(C, 2) case 1: SP_V(C, 1) default: SP_V(C, 0) \
+    }
+    if (a.channel_mode) { SP_CH(true) } else { SP_CH(false) }
+#undef SP_V
+#undef SP_CH
+}
+#endif
+
 // Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
-inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, hipStream_t stream)
+inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, int device, hipStream_t stream)
 {
     if (!lds_kernel_supports(a.n) || a.lut_len > kLdsMaxLut || a.lut_len < 2 || !(a.gray_b <= kLdsMaxGrayB)) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
     // tile height: 32 frames give 128-byte row segments; small images use shorter groups so every CU gets work
     int want = 32;
+#ifdef SP_EXPERIMENT_KNOBS
     static const int cu_env = getenv("SP_CU_LIMIT") ? atoi(getenv("SP_CU_LIMIT")) : 0;   // measurements only (tools/overhead.py)
     if (cu_env > 0 && cu_env < cu_count) cu_count = cu_env;
+#endif
     while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
     const int gf = lds_group_frames(n, want);
     const int groups = (a.width + gf - 1) / gf;
     const LdsLayout lay = lds_layout(n, a.lut_len, gf);
     int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;
-
-#define SP_LAUNCH_V(L, C, P)                                                                                              \
-    {                                                                                                                    \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
-            if (hipFuncSetAttribute((const void *)k_lds_r16<L, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                    160 * 1024) != hipSuccess)                                                           \
-                return SP_ERR_HIP;                                                                                       \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
-        hipLaunchKernelGGL((k_lds_r16<L, C, P>), dim3((unsigned)grid), dim3(kLdsThreads), (size_t)lay.total, stream, a,  \
-                           format, stage_tw, gf, groups);                                                                \
-    }
-#define SP_LAUNCH_CH(L, C)                                                                                               \
-    if (prefetch == 8) SP_LAUNCH_V(L, C, 8) else if (prefetch == 4) SP_LAUNCH_V(L, C, 4) else if (prefetch == 3) SP_LAUNCH_V(L, C, 3)    \
-    else if (prefetch == 2) SP_LAUNCH_V(L, C, 2) else if (prefetch == 1) SP_LAUNCH_V(L, C, 1) else SP_LAUNCH_V(L, C, 0)
-#define SP_LAUNCH(L)                                                                                                     \
-    case L:                                                                                                              \
-        if (a.channel_mode) { SP_LAUNCH_CH(L, true) } else { SP_LAUNCH_CH(L, false) }                                    \
-        break;
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
-    // next-frame register prefetch: frames inside the buffer, 2-, 4- or 8-byte samples
-    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;   // 1, 2, 3, 4, 8 bytes per sample
+    // next-frame register prefetch: frames inside the buffer, 1-, 2-, 3-, 4- or 8-byte samples
+    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;
     // 3-byte samples are fetched as unaligned dwords, one byte low for a frame that ends with the buffer: that frame must not
     // start at byte 0
     if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
     switch (a.levels) {
-        SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8) SP_LAUNCH(9) SP_LAUNCH(10) SP_LAUNCH(11) SP_LAUNCH(12) SP_LAUNCH(13)
+#define SP_L(L) case L: return launch_lds_n<L>(a, format, stage_tw, grid, lay.total, gf, groups, prefetch, device, stream);
+        SP_L(6) SP_L(7) SP_L(8) SP_L(9) SP_L(10) SP_L(11) SP_L(12) SP_L(13)
+#undef SP_L
     default: return SP_ERR_UNSUPPORTED;
     }
-#undef SP_LAUNCH_V
-#undef SP_LAUNCH_CH
-#undef SP_LAUNCH
-    return SP_OK;
 }
 
 }  // namespace spk

@@ -25,6 +25,9 @@ struct FrameArgs {
     const double *cb_edge;       // [1001]
     const uint32_t *lut_rgba;    // [lut_len] packed r | g<<8 | b<<16 | 255<<24
     float gray_a, gray_b, cb_a, cb_b;
+    // k_frames epilogue (sp_host.h Thresholds): t = a + b*log2(abs2) lowered by the margin m, risky when fract(t) >= thr
+    float g2_a, g2_b, g2_thr, g2_m;
+    float c2_a, c2_b, c2_thr, c2_m, c2_lo, c2_hi;
     uint8_t *rgba;               // [4*width*n] or nullptr
     unsigned long long *c_hist;  // [lut_len]   accumulators (zero before every launch, k_finish_frames moves them out)
     unsigned long long *cb_hist; // [1000]

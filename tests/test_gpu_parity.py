@@ -82,7 +82,7 @@ def test_golden_worker_cases_sp_render(pkg, ctx, golden):
     assert not bad, bad[:30]
 
 
-@pytest.mark.parametrize("kernel", ["scratch", "lds"])
+@pytest.mark.parametrize("kernel", ["scratch", "lds", "frames"])
 def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
     """The same vectors through sp_plan_execute with each device kernel forced (device-resident operands)."""
     bad, ran = [], 0
@@ -372,7 +372,7 @@ def test_reply_is_overwritten_not_accumulated(pkg, ctx):
     i = np.arange(256)
     lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
     want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W)
-    for kernel in ("lds", "scratch"):
+    for kernel in ("frames", "lds", "scratch"):
         plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
         plan.force_kernel(kernel)
         d_in = ctx.alloc(data.size)

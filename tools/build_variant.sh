@@ -4,9 +4,5 @@
 set -e
 NAME=$1; EXTRA=$2
 ROOT=$(cd $(dirname $0)/.. && pwd)/spectroplot-js_amd
-B=/tmp/sp_variant_$NAME; mkdir -p $B $ROOT/lib/variants
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -I$ROOT/../include $EXTRA"
-/opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c -o $B/sp_api.o $ROOT/csrc/sp_api.hip
-g++ $FLAGS -c -o $B/sp_host.o $ROOT/csrc/sp_host.cpp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/lib/variants/$NAME.so $B/sp_api.o $B/sp_host.o
+make -s -j8 -C $ROOT BUILD=/tmp/sp_variant_$NAME OUT=lib/variants/$NAME.so EXTRA="$EXTRA"
 echo built $NAME

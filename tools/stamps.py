@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave phase clocks of k_frames from a library built with -DSP_STAMPS (tools/build_variant.sh stamps -DSP_STAMPS).
+   SP_LIB_VARIANT=stamps python3 tools/stamps.py [cfg]"""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from __graft_entry__ import load_package
+pkg = load_package()
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+fmt, lg, n, window, cmap, frames, desc = bench.CONFIGS[cfg]
+S = 1 << lg; sw = bench.SAMPLE_WIDTH[fmt]; W = frames if frames else S // n
+ctx = pkg.Context(0)
+win, weight = pkg.window(window, n)
+lut = bench.load_cmap(cmap)
+plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+plan.force_kernel("frames")
+d_in = ctx.alloc(S * sw)
+ctx.synth_trinoise(d_in, fmt, 0, S, bench.GEN["seed"], bench.GEN["step"], bench.GEN["gshift"], bench.GEN["amp"], bench.GEN["namp"])
+L = len(lut)
+ptrs = [ctx.alloc(max(s, 16)) for s in (4 * W * n, W, W, W, 8 * L, 8000, 16)]
+for _ in range(300):
+    plan.execute(d_in, S * sw, W, *ptrs)
+ctx.synchronize()
+waves = 8 if n > 1024 else int(os.environ.get("SP_WAVES", "8"))
+cnt = 256 * waves * 8
+buf = (ctypes.c_ulonglong * cnt)()
+lib = ctx.lib.L
+lib.sp_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+assert lib.sp_debug_read_stamps(ctx.h, buf, cnt) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(256, waves, 8).astype(np.float64)
+names = ["head+decode", "pass1+xch1(+drain0)", "pass2+xch2", "pass3", "drain+barrier", "epilogue", "loop total", "start clock"]
+tot = a[:, :, 6].mean()
+print("%s: mean cycles per wave over the frame loop (%d frames per wave): %.0f" % (cfg, W // (256 * waves), tot))
+for k in range(6):
+    print("  %-22s %9.0f  %5.1f %%   (min %.0f max %.0f over waves)" % (names[k], a[:, :, k].mean(), 100 * a[:, :, k].mean() / tot, a[:, :, k].min(), a[:, :, k].max()))
+st = a[:, :, 7]
+print("  start skew across the chip: %.0f cycles; per-wave loop total min %.0f max %.0f" % (st.max() - st.min(), a[:, :, 6].min(), a[:, :, 6].max()))
+print("  by wave index (mean loop total):", np.round(a[:, :, 6].mean(axis=0)))
+for k in range(6):
+    print("  by wave index %-20s" % names[k], np.round(a[:, :, k].mean(axis=0)))
