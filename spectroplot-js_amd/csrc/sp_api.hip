@@ -63,6 +63,7 @@ struct sp_context {
     DeviceBuffer in_bytes, out_rgba, render_small;
     sp_plan *cached_plan = nullptr;
     bool acc_dirty = false;      // a request failed between its two kernels: accumulators must be re-initialised
+    int cell_toggle = 0;         // which of the two merged-cell buffers the next k_frames launch counts into
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -85,6 +86,7 @@ struct sp_plan {
     DeviceBuffer tables;            // one allocation, carved below
     const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
     const uint32_t *d_lut = nullptr;
+    const uint16_t *d_cell_g = nullptr, *d_cell_l = nullptr;   // merged-cell ranges per colour index / level (k_frames)
     const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
     int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds_r16, 3 frames
 };
@@ -408,6 +410,8 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
     p->th = th;
     p->th.gray_edge.clear();
     p->th.cb_edge.clear();
+    p->th.cell_g.clear();
+    p->th.cell_l.clear();
     std::vector<uint32_t> lut32((size_t)L);
     for (int i = 0; i < L; i++)
         lut32[(size_t)i] = (uint32_t)p->lut[3 * (size_t)i] | ((uint32_t)p->lut[3 * (size_t)i + 1] << 8)
@@ -428,7 +432,8 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
 
     // one device allocation: [window n][cos half][sin half][gray_edge L][cb_edge 1001][stage_tw 2n doubles][lut L u32]
     const size_t nd = (size_t)n + 2 * (size_t)half + (size_t)L + (SP_CB_HIST_SIZE + 1) + 2 * stage_tw.size();
-    const size_t bytes = nd * sizeof(double) + (size_t)L * sizeof(uint32_t);
+    const size_t cell_u16 = th.cell_g.size() + th.cell_l.size();
+    const size_t bytes = nd * sizeof(double) + (((size_t)L * sizeof(uint32_t) + 7) & ~(size_t)7) + cell_u16 * sizeof(uint16_t);
     rc = p->tables.reserve(bytes);
     if (rc) {
         delete p;
@@ -452,6 +457,13 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
     p->d_stage_tw = (const double2 *)put(stage_tw.data(), 2 * stage_tw.size());
     memcpy(h + o, lut32.data(), (size_t)L * sizeof(uint32_t));
     p->d_lut = (const uint32_t *)(d + o);
+    {
+        const size_t off = o * sizeof(double) + (((size_t)L * sizeof(uint32_t) + 7) & ~(size_t)7);
+        memcpy(host.data() + off, th.cell_g.data(), th.cell_g.size() * sizeof(uint16_t));
+        memcpy(host.data() + off + th.cell_g.size() * sizeof(uint16_t), th.cell_l.data(), th.cell_l.size() * sizeof(uint16_t));
+        p->d_cell_g = (const uint16_t *)((const char *)p->tables.p + off);
+        p->d_cell_l = p->d_cell_g + th.cell_g.size();
+    }
     hipError_t e = hipMemcpyAsync(p->tables.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -572,9 +584,13 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
         const int bins = plan->req.lut_len > SP_CB_HIST_SIZE ? plan->req.lut_len : SP_CB_HIST_SIZE;   // it also moves the histograms
         const int hb = (bins + spk::kFinishThreads - 1) / spk::kFinishThreads;
         if (finish_blocks < hb) finish_blocks = hb;
+        const int cb = (spk2::kMaxCells + spk::kFinishThreads - 1) / spk::kFinishThreads;
+        if (finish_blocks < cb) finish_blocks = cb;
     }
     // [16,32) bit patterns of the extreme |X|^2 of a launch, [64, ...) colour and centi-bel histogram accumulators
-    const size_t acc_bytes = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
+    // ... and two merged-cell buffers for k_frames (one counts while the finish kernel of the previous launch reads the other)
+    const size_t cell_off = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
+    const size_t acc_bytes = cell_off + 2 * spk2::kMaxCells * sizeof(unsigned long long);
     const bool fresh_partial = ctx->partial.cap < acc_bytes;
     rc = ctx->partial.reserve(acc_bytes);
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
@@ -629,6 +645,9 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.mm_acc = (unsigned long long *)((char *)ctx->partial.p + 16);
     a.c_hist = (unsigned long long *)((char *)ctx->partial.p + 64);
     a.cb_hist = a.c_hist + SP_MAX_LUT;
+    unsigned long long *const cell_buf = (unsigned long long *)((char *)ctx->partial.p + cell_off);
+    a.cell_acc = cell_buf + (size_t)ctx->cell_toggle * spk2::kMaxCells;
+    a.cells = plan->th.cells;
 
     const int which = plan_kernel(plan);
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
@@ -688,6 +707,15 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     fa.acc_cb = a.cb_hist;
     fa.out_c = (unsigned long long *)out->c_hist;
     fa.out_cb = (unsigned long long *)out->cb_hist;
+    if (which == 3) {
+        fa.cell_acc = a.cell_acc;
+        fa.cell_clear = cell_buf + (size_t)(ctx->cell_toggle ^ 1) * spk2::kMaxCells;
+        fa.cell_g = plan->d_cell_g;
+        fa.cell_l = plan->d_cell_l;
+        fa.cells = plan->th.cells;
+        fa.cells_cap = spk2::kMaxCells;
+        ctx->cell_toggle ^= 1;
+    }
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);
     SP_HIP(ctx, hipGetLastError());
     ctx->acc_dirty = false;

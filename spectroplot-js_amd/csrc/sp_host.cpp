@@ -179,6 +179,28 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
     // edge tables: their clamp bounds have a fractional part past the threshold
     t.c2_lo = -(float)(0.5 * c_m);
     t.c2_hi = (float)((double)SP_CB_HIST_SIZE - c_m);
+    {
+        // merged cells: an infinite (unreachable) edge is never counted, and the indices behind it own no cell
+        const int32_t end = (lut_len - 1) + SP_CB_HIST_SIZE + 1;
+        auto count_le = [](const std::vector<double> &edge, double v) {   // edges [1..] are non-decreasing
+            int32_t lo = 0, hi = (int32_t)edge.size() - 1;               // number of j >= 1 with edge[j] <= v
+            while (lo < hi) {
+                const int32_t mid = (lo + hi + 1) >> 1;
+                if (edge[(size_t)mid] <= v) lo = mid;
+                else hi = mid - 1;
+            }
+            return lo;
+        };
+        t.cells = end + 2;
+        t.cell_g.assign((size_t)lut_len + 1, (uint16_t)end);
+        t.cell_l.assign(SP_CB_HIST_SIZE + 2, (uint16_t)end);
+        t.cell_g[0] = 0;
+        t.cell_l[0] = 0;
+        for (int32_t g = 1; g < lut_len; g++)
+            if (t.gray_edge[(size_t)g] != spjs::inf()) t.cell_g[(size_t)g] = (uint16_t)(g + count_le(t.cb_edge, t.gray_edge[(size_t)g]));
+        for (int32_t l = 1; l <= SP_CB_HIST_SIZE; l++)
+            if (t.cb_edge[(size_t)l] != spjs::inf()) t.cell_l[(size_t)l] = (uint16_t)(l + count_le(t.gray_edge, t.cb_edge[(size_t)l]));
+    }
     auto fractf_ = [](float v) { return v - std::floor(v); };
     t.frames_ok = g_m < 0.125 && c_m < 0.125 && std::isfinite(t.g2_a) && std::isfinite(t.c2_a) && fractf_(t.c2_lo) >= t.c2_thr
                   && fractf_(t.c2_hi) >= t.c2_thr && t.c2_hi < (float)SP_CB_HIST_SIZE;

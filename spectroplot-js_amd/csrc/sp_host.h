@@ -54,6 +54,13 @@ struct Thresholds {
     float g2_a, g2_b, g2_thr, g2_m;
     float c2_a, c2_b, c2_thr, c2_m, c2_lo, c2_hi;   // c2_lo / c2_hi: clamp bounds of the level value, both past the threshold
     bool frames_ok;
+    // k_frames counts one histogram for both scales: cell = colour index + level.  Both are monotone step functions of abs2, so
+    // their sum steps by one at every edge of either scale and names the merged interval abs2 lies in; the counts of colour index g
+    // are the cells [cell_g[g], cell_g[g+1]), those of level l the cells [cell_l[l], cell_l[l+1]).  Two more cells take the keys
+    // that are not monotone (worker.js:105: -inf / NaN dB -> bin 0 with colour 0, +inf dB -> bin 0 with the last colour).
+    std::vector<uint16_t> cell_g;    // [lut_len + 1]
+    std::vector<uint16_t> cell_l;    // [SP_CB_HIST_SIZE + 2]
+    int32_t cells;                   // lut_len + SP_CB_HIST_SIZE + 2 (the last two: special keys)
 };
 Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len);
 

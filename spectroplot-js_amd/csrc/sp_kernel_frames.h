@@ -49,9 +49,8 @@ inline constexpr Tw16 kTw16Host[8] = {
     {-0x1.d906bcf328d46p-1, 0x1.87de2a6aea965p-2},
 };
 
-constexpr int kClipWords = 64;        // lane-private histogram words on either side of the colour histogram
-constexpr int kCbTrashWords = 64;     // lane-private words behind the level histogram (dropped keys)
 constexpr int kMmSlotsMax = 4;
+constexpr int kMaxCells = kLdsMaxLut + SP_CB_HIST_SIZE + 2;   // merged histogram cells (sp_host.h Thresholds)
 
 __host__ __device__ inline constexpr int mm_slots(int n)
 {
@@ -79,8 +78,7 @@ __host__ __device__ inline int group_frames_for(int n, int want, int threads)
 }
 
 struct Layout {
-    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_chist, off_cbhist, off_win, total;
-    int chist_words, cbhist_words;
+    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_win, total;
 };
 
 __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds)
@@ -95,10 +93,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     l.off_mm = o;     o += group_frames * mm_slots(n) * 2 * 8;
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
-    l.chist_words = lut_len + 2 * kClipWords;
-    l.cbhist_words = SP_CB_HIST_SIZE + 1 + kCbTrashWords;
-    l.off_chist = o;  o += l.chist_words * 4;
-    l.off_cbhist = o; o += l.cbhist_words * 4;
+    l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
     o = (o + 7) & ~7;
     l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
@@ -200,11 +195,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     unsigned long long *s_mm = (unsigned long long *)(smem + lay.off_mm);
     unsigned char *s_tile = smem + lay.off_tile;
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
-    unsigned int *s_chist = (unsigned int *)(smem + lay.off_chist);      // word w counts colour index w - kClipWords
-    unsigned int *s_cbhist = (unsigned int *)(smem + lay.off_cbhist);    // word l counts level l (bin 999 - l); words > 1000: dropped keys
+    unsigned int *s_cells = (unsigned int *)(smem + lay.off_cells);      // word c counts the pixels with colour index + level == c
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    [[maybe_unused]] const int lane = tid & 63;
     const int fs = tid / T;                         // frame slot within a round
     const int tl = tid % T;                         // thread within the frame
     double *xbuf = s_xch + fs * (N + N / 16);
@@ -265,8 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                 if (i <= SP_CB_HIST_SIZE) ((double *)(smem + lay.off_cbedge))[i] = cb_r[k];
             }
         }
-        for (int i = tid; i < lay.chist_words; i += kThreads) s_chist[i] = 0;
-        for (int i = tid; i < lay.cbhist_words; i += kThreads) s_cbhist[i] = 0;
+        for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
     }
 
     constexpr bool WIN_LDS = lds_win_in_lds(N);
@@ -292,9 +285,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     // epilogue constants (sp_host.cpp build_thresholds): t = a + b*log2(|X|^2), already lowered by the margin
     const float g_a = a.g2_a, g_b = a.g2_b, g_thr = a.g2_thr, g_m = a.g2_m;
     const float c_a = a.c2_a, c_b = a.c2_b, c_thr = a.c2_thr, c_m = a.c2_m, c_lo = a.c2_lo, c_hi = a.c2_hi;
-    // lane-dependent clamp bounds of the colour value: a clipped pixel of lane l counts in word -(l+1) or cmax+1+l
-    const float g_lo = -0.5f - (float)lane, g_hi = (float)cmax + 1.5f + (float)lane;
-    unsigned int *const chist0 = s_chist + kClipWords;
+    // clamp bounds of the colour value: clipped pixels sit in the middle of the first / last step, far from the risky zone
+    const float g_lo = 0.5f, g_hi = (float)cmax + 0.5f;
+    const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
     auto drain = [&](const int x0, const int part, const int nparts) {
@@ -319,7 +312,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
         if (a.rgba) {
             if (!a.waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
-                // a thread owns 4 consecutive bins x 4 consecutive frames; the threads of a row cover one contiguous run
+                // The tile keeps a frame as the epilogue leaves it: 16 bytes per thread, byte e = bin tl + e*T.  A write-out item is
+                // one of a thread's four dwords (bins tl + (4*e4 + j)*T, j = 0..3) of 4 consecutive frames: four 16-byte stores in four
+                // rows; the items of a row segment (8 frame quads) sit in lanes 4 apart, and a wave's dword reads are conflict-free
+                // (tile pitch = 1 dword mod 8).
                 const int quads = group_frames / 4;
                 const int items = (N / 4) * quads;
                 for (int it0 = tid + part * 2 * kThreads; it0 < items; it0 += nparts * 2 * kThreads) {
@@ -329,11 +325,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                     for (int u = 0; u < 2; u++) {
                         const int it = it0 + u * kThreads;
                         const int itc = it < items ? it : it0;
-                        const int fq = itc % quads, bq = itc / quads;
-                        i0v[u] = bq * 4;
+                        const int e4 = itc & 3, fq = (itc >> 2) % quads, tq = (itc >> 2) / quads;   // tq: thread of the frame
+                        i0v[u] = tq + 4 * e4 * T;
                         xav[u] = it < items ? x0 + fq * 4 : a.width;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
+                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + tq * 16 + e4 * 4);
                     }
                     uint32_t px[2][4][4];
 #pragma unroll
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                         if (xa >= a.width) continue;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const int i = i0v[u] + j;
+                            const int i = i0v[u] + j * T;
                             const int y = (N / 2 - i) & (N - 1);
                             uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
                             if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
@@ -371,7 +367,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                     const unsigned char *row = s_tile + f * tile_pitch;
                     uint32_t px[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) px[k] = s_lut[row[(c4 + k + N / 2 + 1) & (N - 1)]];
+                    for (int k = 0; k < 4; k++) {
+                        const int i = (c4 + k + N / 2 + 1) & (N - 1);
+                        px[k] = s_lut[row[(i & (T - 1)) * 16 + (i >> (LOG2N - 4))]];
+                    }
                     uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
                     *(uint4 *)dst = make_uint4(px[0], px[1], px[2], px[3]);
                 }
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             // Lanes past that threshold (and centi-bel values at or beyond the ends of the scale, +-inf and NaN among them, whose
             // clamp bounds lie past it by construction) take the exact edge compare.
             double mn = spjs::inf(), mx = 0.0;
-            unsigned char *trow = s_tile + fr * tile_pitch;
+            uint32_t *trow = (uint32_t *)(s_tile + fr * tile_pitch + tl * 16);
 #ifdef SP_ABL_NOEPI
             asm volatile("" ::"v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(re[4]), "v"(re[5]), "v"(re[6]), "v"(re[7]), "v"(re[8]), "v"(re[9]), "v"(re[10]), "v"(re[11]), "v"(re[12]), "v"(re[13]), "v"(re[14]), "v"(re[15]));
             asm volatile("" ::"v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(im[4]), "v"(im[5]), "v"(im[6]), "v"(im[7]), "v"(im[8]), "v"(im[9]), "v"(im[10]), "v"(im[11]), "v"(im[12]), "v"(im[13]), "v"(im[14]), "v"(im[15]));
@@ -560,42 +559,61 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #else
             if (live) {
 #endif
+                // four bins at a time: four independent chains for the VALU, one branch, one packed tile dword
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const double abs2 = re[e] * re[e] + im[e] * im[e];                 // worker.js:92
-                    mn = min_nn(mn, abs2);
-                    mx = max_nn(mx, abs2);
-                    const float l2 = __log2f((float)abs2);
-                    const float tg = __builtin_amdgcn_fmed3f(fmaf(g_b, l2, g_a), g_lo, g_hi);
-                    const float tc = __builtin_amdgcn_fmed3f(fmaf(c_b, l2, c_a), c_lo, c_hi);
-                    int gi = floor_to_int(tg);                                         // colour index, or a lane-private clip word
-                    int lv = floor_to_int(tc);                                         // level = 999 - centi-bel bin
-                    const bool risky = !(__builtin_amdgcn_fractf(tg) < g_thr) || !(__builtin_amdgcn_fractf(tc) < c_thr);
-                    if (__builtin_expect(__ballot(risky) != 0ull, 0)) {
-                        if (risky) {
-                            // nearest edge on either scale, then one exact comparison each (edges: sp_host.h Thresholds)
-                            int rg = (int)rintf(tg + g_m);
-                            rg = rg < 1 ? 1 : (rg > cmax ? cmax : rg);
-                            int rc = (int)rintf(tc + c_m);
-                            rc = rc < 1 ? 1 : (rc > SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE : rc);
-                            const double eg = edge_g[rg], ec = edge_cb[rc];
-                            gi = abs2 >= eg ? rg : rg - 1;                             // NaN: every comparison false -> index 0 below
-                            lv = abs2 >= ec ? rc : rc - 1;
-                            if (!(abs2 == abs2)) gi = 0;
-                            // -inf / +inf / NaN dB: ToInt32 gives key 0, i.e. bin 0 = level 999                     worker.js:105
-                            if (!(abs2 > 0.0) || abs2 == spjs::inf()) lv = SP_CB_HIST_SIZE - 1;
-                            if (lv == SP_CB_HIST_SIZE) lv = SP_CB_HIST_SIZE + 1 + lane;    // negative key: dropped
+                for (int q = 0; q < 4; q++) {
+                    double abs2[4];
+                    float tg[4], tc[4];
+                    int gi[4], cell[4];
+                    bool risky[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int e = 4 * q + k;
+                        abs2[k] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
+                        mn = min_nn(mn, abs2[k]);
+                        mx = max_nn(mx, abs2[k]);
+                        const float l2 = __log2f((float)abs2[k]);
+                        tg[k] = __builtin_amdgcn_fmed3f(fmaf(g_b, l2, g_a), g_lo, g_hi);
+                        tc[k] = __builtin_amdgcn_fmed3f(fmaf(c_b, l2, c_a), c_lo, c_hi);
+                        gi[k] = floor_to_int(tg[k]);                                   // colour index
+                        cell[k] = gi[k] + floor_to_int(tc[k]);                         // + level (= 999 - centi-bel bin)
+                        risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < g_thr) || !(__builtin_amdgcn_fractf(tc[k]) < c_thr);
+                    }
+                    if (__builtin_expect(__ballot(risky[0] || risky[1] || risky[2] || risky[3]) != 0ull, 0)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (risky[k]) {
+                                // nearest edge on either scale, then one exact comparison each (edges: sp_host.h Thresholds)
+                                int rg = (int)rintf(tg[k] + g_m);
+                                rg = rg < 1 ? 1 : (rg > cmax ? cmax : rg);
+                                int rc = (int)rintf(tc[k] + c_m);
+                                rc = rc < 1 ? 1 : (rc > SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE : rc);
+                                const double eg = edge_g[rg], ec = edge_cb[rc];
+                                int g = abs2[k] >= eg ? rg : rg - 1;
+                                int c = g + (abs2[k] >= ec ? rc : rc - 1);
+                                // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
+                                if (!(abs2[k] > 0.0)) {
+                                    g = 0;
+                                    c = cell_sp0;
+                                } else if (abs2[k] == spjs::inf()) {
+                                    c = cell_sp0 + 1;
+                                }
+                                gi[k] = g;
+                                cell[k] = c;
+                            }
                         }
                     }
 #ifndef SP_ABL_NOTILE
-                    trow[tl + e * T] = (unsigned char)min(max(gi, 0), cmax);
+                    trow[q] = (uint32_t)gi[0] | ((uint32_t)gi[1] << 8) | ((uint32_t)gi[2] << 16) | ((uint32_t)gi[3] << 24);
 #endif
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
 #ifndef SP_ABL_NOHIST
-                    atomicAdd(&chist0[gi], 1u);
-                    atomicAdd(&s_cbhist[lv], 1u);
+                        atomicAdd(&s_cells[cell[k]], 1u);
 #else
-                    asm volatile("" ::"v"(gi), "v"(lv));
+                        asm volatile("" ::"v"(cell[k]));
 #endif
+                    }
                 }
                 unsigned long long *slot = s_mm + 2 * (fr * MMS + (tl & (MMS - 1)));
                 atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
@@ -619,17 +637,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #endif
     // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
     lds_barrier();
-    for (int i = tid; i < a.lut_len; i += kThreads) {
-        unsigned int v = chist0[i];
-        if (i == 0)
-            for (int k = 1; k <= kClipWords; k++) v += chist0[-k];
-        if (i == cmax)
-            for (int k = 1; k <= kClipWords; k++) v += chist0[cmax + k];
-        if (v) atomicAdd(&a.c_hist[i], (unsigned long long)v);
-    }
-    for (int i = tid; i < SP_CB_HIST_SIZE; i += kThreads) {
-        const unsigned int v = s_cbhist[i];
-        if (v) atomicAdd(&a.cb_hist[SP_CB_HIST_SIZE - 1 - i], (unsigned long long)v);
+    for (int i = tid; i < a.cells; i += kThreads) {
+        const unsigned int v = s_cells[i];
+        if (v) atomicAdd(&a.cell_acc[i], (unsigned long long)v);
     }
     if (drain_x0 >= 0) {
         drain(drain_x0, 0, 1);

@@ -148,6 +148,13 @@ struct FinishArgs {
     int32_t lut_len;
     unsigned long long *acc_c, *acc_cb;
     unsigned long long *out_c, *out_cb;   // or nullptr
+    // k_frames: merged cells (sp_host.h Thresholds) instead of the two accumulators.  cell_acc is this launch's buffer,
+    // cell_clear the other one of the pair, which the NEXT launch counts into: a cell is read by two threads here (its colour
+    // index and its level), so the buffer that is read cannot be the one that is zeroed.
+    const unsigned long long *cell_acc;
+    unsigned long long *cell_clear;
+    const uint16_t *cell_g, *cell_l;
+    int32_t cells, cells_cap;
 };
 
 // store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
@@ -206,7 +213,50 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
             a.gauge_amps[x] = clamp_u8(0.5 + (a.range + amp) * 256 / a.range);
         }
     }
-    {
+    if (a.cell_acc) {
+        // merged cells -> the two histograms: every count is a difference of two prefix sums over the cells.  The workgroups that
+        // own histogram outputs (the first few) build the prefix in LDS: 8 consecutive cells per thread, then a scan of the 256
+        // partial sums.
+        const int gi = blockIdx.x * kFinishThreads + threadIdx.x;
+        constexpr int kPer = 8;                                          // 256 threads x 8 >= the largest cell count
+        __shared__ unsigned long long s_pre[kFinishThreads * kPer + 1];
+        __shared__ unsigned long long s_part[kFinishThreads];
+        const bool owner = blockIdx.x * kFinishThreads < (a.lut_len > SP_CB_HIST_SIZE ? a.lut_len : SP_CB_HIST_SIZE);
+        if (owner) {
+            unsigned long long v[kPer], run = 0;
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int c = threadIdx.x * kPer + k;
+                v[k] = c < a.cells ? a.cell_acc[c] : 0ull;
+                run += v[k];
+            }
+            s_part[threadIdx.x] = run;
+            __syncthreads();
+            for (int d = 1; d < kFinishThreads; d <<= 1) {                // inclusive scan of the partial sums
+                const unsigned long long add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0ull;
+                __syncthreads();
+                s_part[threadIdx.x] += add;
+                __syncthreads();
+            }
+            unsigned long long base = s_part[threadIdx.x] - run;          // sum of the cells below this thread's first
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                s_pre[threadIdx.x * kPer + k] = base;                     // s_pre[c] = sum of cells [0, c)
+                base += v[k];
+            }
+            if (threadIdx.x == kFinishThreads - 1) s_pre[kFinishThreads * kPer] = base;
+            __syncthreads();
+            const int sp0 = a.cells - 2, sp1 = a.cells - 1;
+            const unsigned long long n0 = s_pre[sp0 + 1] - s_pre[sp0], n1 = s_pre[sp1 + 1] - s_pre[sp1];
+            if (gi < a.lut_len && a.out_c)
+                a.out_c[gi] = s_pre[a.cell_g[gi + 1]] - s_pre[a.cell_g[gi]] + (gi == 0 ? n0 : 0ull) + (gi == a.lut_len - 1 ? n1 : 0ull);
+            if (gi < SP_CB_HIST_SIZE && a.out_cb) {
+                const int l = SP_CB_HIST_SIZE - 1 - gi;                   // bin gi counts level 999 - gi
+                a.out_cb[gi] = s_pre[a.cell_l[l + 1]] - s_pre[a.cell_l[l]] + (gi == 0 ? n0 + n1 : 0ull);
+            }
+        }
+        if (gi < a.cells_cap) a.cell_clear[gi] = 0ull;   // the whole buffer: the next plan may use more cells than this one
+    } else {
         // histograms: accumulators -> reply, accumulators back to zero
         const int gi = blockIdx.x * kFinishThreads + threadIdx.x;
         if (gi < a.lut_len) {

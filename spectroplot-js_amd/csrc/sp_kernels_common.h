@@ -35,6 +35,8 @@ struct FrameArgs {
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
     unsigned long long *mm_acc;  // [2] bit patterns of the min / max of abs2 over all frames ({+inf, 0} before every launch)
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
+    unsigned long long *cell_acc;   // k_frames: [cells] merged-cell accumulators (zero before every launch)
+    int32_t cells;
 };
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
