@@ -584,13 +584,14 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
         const int bins = plan->req.lut_len > SP_CB_HIST_SIZE ? plan->req.lut_len : SP_CB_HIST_SIZE;   // it also moves the histograms
         const int hb = (bins + spk::kFinishThreads - 1) / spk::kFinishThreads;
         if (finish_blocks < hb) finish_blocks = hb;
-        const int cb = (spk2::kMaxCells + spk::kFinishThreads - 1) / spk::kFinishThreads;
+        const int cb = (spk2::kMaxCells * spk2::kCellCopies + spk::kFinishThreads - 1) / spk::kFinishThreads;
         if (finish_blocks < cb) finish_blocks = cb;
     }
     // [16,32) bit patterns of the extreme |X|^2 of a launch, [64, ...) colour and centi-bel histogram accumulators
     // ... and two merged-cell buffers for k_frames (one counts while the finish kernel of the previous launch reads the other)
     const size_t cell_off = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
-    const size_t acc_bytes = cell_off + 2 * spk2::kMaxCells * sizeof(unsigned long long);
+    const size_t cell_buf_words = (size_t)spk2::kMaxCells * spk2::kCellCopies;
+    const size_t acc_bytes = cell_off + 2 * cell_buf_words * sizeof(unsigned long long);
     const bool fresh_partial = ctx->partial.cap < acc_bytes;
     rc = ctx->partial.reserve(acc_bytes);
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
@@ -646,8 +647,11 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.c_hist = (unsigned long long *)((char *)ctx->partial.p + 64);
     a.cb_hist = a.c_hist + SP_MAX_LUT;
     unsigned long long *const cell_buf = (unsigned long long *)((char *)ctx->partial.p + cell_off);
-    a.cell_acc = cell_buf + (size_t)ctx->cell_toggle * spk2::kMaxCells;
+    a.cell_acc = cell_buf + (size_t)ctx->cell_toggle * cell_buf_words;
     a.cells = plan->th.cells;
+    a.cells_cap = spk2::kMaxCells;
+    a.rgba_fast = out->rgba && ((uintptr_t)out->rgba & 15) == 0 && (width & 3) == 0 && width < (1 << 24)
+                  && (double)width * (double)n * 4.0 <= 4294967296.0;
 
     const int which = plan_kernel(plan);
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
@@ -709,11 +713,12 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     fa.out_cb = (unsigned long long *)out->cb_hist;
     if (which == 3) {
         fa.cell_acc = a.cell_acc;
-        fa.cell_clear = cell_buf + (size_t)(ctx->cell_toggle ^ 1) * spk2::kMaxCells;
+        fa.cell_clear = cell_buf + (size_t)(ctx->cell_toggle ^ 1) * cell_buf_words;
         fa.cell_g = plan->d_cell_g;
         fa.cell_l = plan->d_cell_l;
         fa.cells = plan->th.cells;
         fa.cells_cap = spk2::kMaxCells;
+        fa.cell_copies = spk2::kCellCopies;
         ctx->cell_toggle ^= 1;
     }
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);

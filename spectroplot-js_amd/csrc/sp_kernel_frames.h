@@ -51,6 +51,7 @@ inline constexpr Tw16 kTw16Host[8] = {
 
 constexpr int kMmSlotsMax = 4;
 constexpr int kMaxCells = kLdsMaxLut + SP_CB_HIST_SIZE + 2;   // merged histogram cells (sp_host.h Thresholds)
+constexpr int kCellCopies = 8;                               // accumulator copies, one per XCD
 
 __host__ __device__ inline constexpr int mm_slots(int n)
 {
@@ -264,10 +265,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 
     constexpr bool WIN_LDS = lds_win_in_lds(N);
     double *s_win = (double *)(smem + lay.off_win);
-    const double *const wbase = s_win + (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
+    const double *const wbase = s_win + tl;   // stored as the threads read it: entry e*T + tl = taper[rev4(e)*T + rev(tl)]
     double win_reg[WIN_LDS ? 1 : 16];
     if constexpr (WIN_LDS) {
-        for (int i = tid; i < N; i += kThreads) s_win[i] = a.window[i];
+        for (int i = tid; i < N; i += kThreads) {
+            const int e = i / T, t = i % T;
+            s_win[i] = a.window[rev4(e) * T + (int)(__brev((unsigned)t) >> (32 - (LOG2N - 4)))];
+        }
     } else {
         const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
 #pragma unroll
@@ -337,7 +341,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #pragma unroll
                         for (int j = 0; j < 4; j++)
 #pragma unroll
+#ifdef SP_ABL_NOLUT
+                            for (int k = 0; k < 4; k++) px[u][j][k] = ((gb[u][k] >> (8 * j)) & 0xff) * 0x010101u | 0xff000000u;
+#else
                             for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
+#endif
+                    if (a.rgba_fast) {
+                        // rows are 16-byte aligned, the width is a multiple of 4 and the image is below 4 GiB: 32-bit offsets from the
+                        // uniform base (24-bit multiplies), no per-store checks
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const int xa = xav[u];
+                            if (xa >= a.width) continue;
+                            const unsigned y0 = (unsigned)(N / 2 - i0v[u]) & (N - 1);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const unsigned y = (y0 - (unsigned)(j * T)) & (N - 1);
+                                const unsigned off = (__umul24(y, (unsigned)a.width) + (unsigned)xa) * 4u;
+#ifdef SP_ABL_NOSTORE
+                                if (px[u][j][0] != 0x12345678u) continue;
+#endif
+                                *(uint4 *)(a.rgba + off) = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int xa = xav[u];
@@ -347,6 +375,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                             const int i = i0v[u] + j * T;
                             const int y = (N / 2 - i) & (N - 1);
                             uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+#ifdef SP_ABL_NOSTORE
+                            if (px[u][j][0] != 0x12345678u) continue;
+#endif
                             if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
                                 *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             } else {
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     };
     int drain_x0 = -1;
 #ifdef SP_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64(), stamp_slow = 0;
     const unsigned long long stamp_begin = stamp_last;
 #endif
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             double win[16];
             bool nonfinite = true;   // wave-uniform
 #pragma unroll
-            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[rev4(e) * T] : win_reg[WIN_LDS ? 0 : e];
+            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
             const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF && LATE_PF) request(xr);
             if constexpr (PF) {
@@ -478,8 +509,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
                     PassTw<WS2, 9, STAGED ? 8 : E2> tw2;
                     if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
-                    exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
-                    exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+#ifndef SP_X_LDS_E2
+                    if constexpr (LOG2N == 9 || LOG2N == 10) {
+                        // two register bits against lane bits 4 / 5: v_permlane16_swap / v_permlane32_swap.  The swaps cost the VALU
+                        // about what the LDS round trip costs the LDS pipe (measured: 1.2 % of the kernel in favour of the swaps)
+                        exchange_permlane<LOG2N>(re);
+                        exchange_permlane<LOG2N>(im);
+                    } else
+#endif
+                    {
+                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
+                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                    }
                     SP_STAMP(2)   // second pass, second exchange
                     if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
                     else fft_pass<WS2, 9, E2>(re, im, tw2);
@@ -580,6 +621,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                         risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < g_thr) || !(__builtin_amdgcn_fractf(tc[k]) < c_thr);
                     }
                     if (__builtin_expect(__ballot(risky[0] || risky[1] || risky[2] || risky[3]) != 0ull, 0)) {
+#ifdef SP_STAMPS
+                        stamp_slow++;
+#endif
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             if (risky[k]) {
@@ -631,7 +675,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 8;
             for (int k = 0; k < 6; k++) dst[k] = stamp_sum[k];
             dst[6] = loop_end - stamp_begin;
-            dst[7] = stamp_begin;
+            dst[7] = stamp_slow;
         }
     }
 #endif
@@ -639,7 +683,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     lds_barrier();
     for (int i = tid; i < a.cells; i += kThreads) {
         const unsigned int v = s_cells[i];
-        if (v) atomicAdd(&a.cell_acc[i], (unsigned long long)v);
+        // one copy per XCD (workgroups b and b + 8 share one): 32 adders per word instead of 256
+        if (v) atomicAdd(&a.cell_acc[(size_t)xcd * a.cells_cap + i], (unsigned long long)v);
     }
     if (drain_x0 >= 0) {
         drain(drain_x0, 0, 1);

@@ -154,7 +154,7 @@ struct FinishArgs {
     const unsigned long long *cell_acc;
     unsigned long long *cell_clear;
     const uint16_t *cell_g, *cell_l;
-    int32_t cells, cells_cap;
+    int32_t cells, cells_cap, cell_copies;
 };
 
 // store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
@@ -223,13 +223,24 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
         __shared__ unsigned long long s_part[kFinishThreads];
         const bool owner = blockIdx.x * kFinishThreads < (a.lut_len > SP_CB_HIST_SIZE ? a.lut_len : SP_CB_HIST_SIZE);
         if (owner) {
+            // the XCD copies of a cell are summed with coalesced loads (thread t takes cells t, t + 256, ...), then every thread picks
+            // up its 8 consecutive cells from LDS
+            for (int c = threadIdx.x; c < kFinishThreads * kPer; c += kFinishThreads) {
+                unsigned long long sum = 0ull;
+                if (c < a.cells) {
+#pragma unroll 8
+                    for (int x = 0; x < a.cell_copies; x++) sum += a.cell_acc[(size_t)x * a.cells_cap + c];
+                }
+                s_pre[c] = sum;
+            }
+            __syncthreads();
             unsigned long long v[kPer], run = 0;
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                const int c = threadIdx.x * kPer + k;
-                v[k] = c < a.cells ? a.cell_acc[c] : 0ull;
+                v[k] = s_pre[threadIdx.x * kPer + k];
                 run += v[k];
             }
+            __syncthreads();
             s_part[threadIdx.x] = run;
             __syncthreads();
             for (int d = 1; d < kFinishThreads; d <<= 1) {                // inclusive scan of the partial sums
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
                 a.out_cb[gi] = s_pre[a.cell_l[l + 1]] - s_pre[a.cell_l[l]] + (gi == 0 ? n0 + n1 : 0ull);
             }
         }
-        if (gi < a.cells_cap) a.cell_clear[gi] = 0ull;   // the whole buffer: the next plan may use more cells than this one
+        if (gi < a.cells_cap * a.cell_copies) a.cell_clear[gi] = 0ull;   // the whole buffer: the next plan may use more cells than this one
     } else {
         // histograms: accumulators -> reply, accumulators back to zero
         const int gi = blockIdx.x * kFinishThreads + threadIdx.x;

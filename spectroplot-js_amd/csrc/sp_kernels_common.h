@@ -35,8 +35,9 @@ struct FrameArgs {
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
     unsigned long long *mm_acc;  // [2] bit patterns of the min / max of abs2 over all frames ({+inf, 0} before every launch)
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
-    unsigned long long *cell_acc;   // k_frames: [cells] merged-cell accumulators (zero before every launch)
-    int32_t cells;
+    unsigned long long *cell_acc;   // k_frames: [8][cells_cap] merged-cell accumulators, one copy per XCD (zero before every launch)
+    int32_t cells, cells_cap;
+    int32_t rgba_fast;           // rgba 16-byte aligned, width a multiple of 4 and < 2^24, image below 4 GiB
 };
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72

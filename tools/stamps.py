@@ -36,8 +36,8 @@ tot = a[:, :, 6].mean()
 print("%s: mean cycles per wave over the frame loop (%d frames per wave): %.0f" % (cfg, W // (256 * waves), tot))
 for k in range(6):
     print("  %-22s %9.0f  %5.1f %%   (min %.0f max %.0f over waves)" % (names[k], a[:, :, k].mean(), 100 * a[:, :, k].mean() / tot, a[:, :, k].min(), a[:, :, k].max()))
-st = a[:, :, 7]
-print("  start skew across the chip: %.0f cycles; per-wave loop total min %.0f max %.0f" % (st.max() - st.min(), a[:, :, 6].min(), a[:, :, 6].max()))
+print("  exact-edge path taken %.2f times per frame per wave (4 batches of 4 bins per frame); per-wave loop total min %.0f max %.0f"
+      % (a[:, :, 7].mean() / (W / (256.0 * waves)), a[:, :, 6].min(), a[:, :, 6].max()))
 print("  by wave index (mean loop total):", np.round(a[:, :, 6].mean(axis=0)))
 for k in range(6):
     print("  by wave index %-20s" % names[k], np.round(a[:, :, k].mean(axis=0)))
