@@ -154,19 +154,23 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
 
     // ---- k_frames: floor(a + b*L) with L = v_log_f32((float)abs2), all in f32 -------------------------------------------------
     // real-valued position of abs2:  colour 0.5 + color_max + per_db*dbfs,  level 999.5 + 10*rel_db  (dbfs = c*log2(abs2) + ...)
-    // error of the f32 evaluation, for abs2 in [2^-128, 2^128] (everything outside is clipped on both scales, see
-    // plan_frames_capable):  (float)abs2: 2^-24 relative = 2^-24 / ln 2 in L;  v_log_f32: <= 1 ulp of L (tests/test_gpu_parity.py
-    // sweeps it), counted as 2 ulp of 128 = 2^-16;  b rounded to f32: |b| * 2^-24 * 128;  a rounded to f32: (|a| + 1) * 2^-24;
-    // the fma's own rounding: half an ulp of the largest value that is not clamped (colour: lut_len + 64, level: 1024).
-    // The reference's own arithmetic places its steps within ~1e-12 of the real-valued positions (f64).  Safety factor 1.25.
-    auto margin = [&](double a, double b, double tmax) {
-        const double e_l = 0x1p-24 / 0.6931471805599453 + 0x1p-16;
-        const double ulp_t = std::ldexp(1.0, std::ilogb(tmax) - 23);
-        return 1.25 * (std::fabs(b) * e_l + std::fabs(b) * 0x1p-24 * 128.0 + (std::fabs(a) + 1.0) * 0x1p-24 + 0.5 * ulp_t) + 1e-7;
-    };
+    // Only lanes whose level value lies inside its clamp range [0, 1000) take the fast path (the others are decided against the
+    // edge tables whatever the colour test says), i.e. L in [-c_a/c_b, (1000 - c_a)/c_b] =: [-l_max, l_max] (plus one for slack).
+    // Error of the f32 evaluation there:  (float)abs2: 2^-24 relative = 2^-24 / ln 2 in L;  v_log_f32: at most 1.0 ulp of its result
+    // over every positive normal f32 (tools/log_error.hip, profiles/r02_v_log_f32_error.txt);  b rounded to f32: |b| * 2^-24 * l_max;
+    // a rounded to f32: (|a| + 1) * 2^-24;  the fma's own rounding: half an ulp of the largest value that is not clamped (colour:
+    // lut_len, level: 1024).  The reference's own arithmetic places its steps within ~1e-12 of the real-valued positions (f64).
+    // Safety factor 1.25.
     const double g_a = 0.5 + pm.color_max + per_db * (pm.block_norm_db + pm.gain), g_b = per_db * c;
     const double c_a = (SP_CB_HIST_SIZE - 0.5) + 10.0 * pm.block_norm_db, c_b = 10.0 * c;
-    const double g_m = margin(g_a, g_b, (double)lut_len + 64.0), c_m = margin(c_a, c_b, 1024.0);
+    const double l_max = std::fmax(std::fabs(-c_a / c_b), std::fabs((SP_CB_HIST_SIZE - c_a) / c_b)) + 1.0;
+    auto margin = [&](double a, double b, double tmax) {
+        const double ulp_l = std::ldexp(1.0, std::ilogb(l_max) - 23);
+        const double e_l = 0x1p-24 / 0.6931471805599453 + ulp_l;
+        const double ulp_t = std::ldexp(1.0, std::ilogb(tmax) - 23);
+        return 1.25 * (std::fabs(b) * e_l + std::fabs(b) * 0x1p-24 * l_max + (std::fabs(a) + 1.0) * 0x1p-24 + 0.5 * ulp_t) + 1e-7;
+    };
+    const double g_m = margin(g_a, g_b, (double)lut_len), c_m = margin(c_a, c_b, 1024.0);
     t.g2_a = (float)(g_a - g_m);
     t.g2_b = (float)g_b;
     t.g2_m = (float)g_m;
@@ -202,7 +206,7 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
             if (t.cb_edge[(size_t)l] != spjs::inf()) t.cell_l[(size_t)l] = (uint16_t)(l + count_le(t.gray_edge, t.cb_edge[(size_t)l]));
     }
     auto fractf_ = [](float v) { return v - std::floor(v); };
-    t.frames_ok = g_m < 0.125 && c_m < 0.125 && std::isfinite(t.g2_a) && std::isfinite(t.c2_a) && fractf_(t.c2_lo) >= t.c2_thr
+    t.frames_ok = g_m < 0.125 && c_m < 0.125 && l_max < 120.0 && std::isfinite(t.g2_a) && std::isfinite(t.c2_a) && fractf_(t.c2_lo) >= t.c2_thr
                   && fractf_(t.c2_hi) >= t.c2_thr && t.c2_hi < (float)SP_CB_HIST_SIZE;
     return t;
 }

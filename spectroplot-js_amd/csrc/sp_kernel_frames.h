@@ -101,6 +101,22 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     return l;
 }
 
+// v_min_f64 / v_max_f64 as single instructions: fmin() / fmax() first quiet a possible signalling NaN in each operand with a
+// v_max_f64 x, x, x of its own, three instructions per call.  The hardware minimum / maximum already ignores a (quiet) NaN
+// operand, which is all the frame extremes need (worker.js:102-103: comparisons with NaN are false).
+__device__ inline double min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ inline double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // First register pass: stages 1-4 inside window [0, 4) with literal twiddles.
 template <bool TRIV>
 __device__ inline void fft_pass1(double (&re)[16], double (&im)[16])
@@ -591,7 +607,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             // scale (sp_host.cpp); a and the clamp bounds are lowered by m, so floor(t) is exact unless fract(t) >= 1 - 2m.
             // Lanes past that threshold (and centi-bel values at or beyond the ends of the scale, +-inf and NaN among them, whose
             // clamp bounds lie past it by construction) take the exact edge compare.
-            double mn = spjs::inf(), mx = 0.0;
+            // four independent min / max chains (one per bin of a batch): a dependent f64 operation waits several issue slots
+            double mn4[4] = {spjs::inf(), spjs::inf(), spjs::inf(), spjs::inf()}, mx4[4] = {0.0, 0.0, 0.0, 0.0};
             uint32_t *trow = (uint32_t *)(s_tile + fr * tile_pitch + tl * 16);
 #ifdef SP_ABL_NOEPI
             asm volatile("" ::"v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(re[4]), "v"(re[5]), "v"(re[6]), "v"(re[7]), "v"(re[8]), "v"(re[9]), "v"(re[10]), "v"(re[11]), "v"(re[12]), "v"(re[13]), "v"(re[14]), "v"(re[15]));
@@ -607,44 +624,77 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                     float tg[4], tc[4];
                     int gi[4], cell[4];
                     bool risky[4];
+                    // written stage by stage: the four chains are independent, and every step of a chain waits on the one before
+                    float l2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) abs2[k] = re[4 * q + k] * re[4 * q + k] + im[4 * q + k] * im[4 * q + k];   // worker.js:92
+#pragma unroll
+                    for (int k = 0; k < 4; k++) l2[k] = (float)abs2[k];
+#pragma unroll
+#ifndef SP_ABL_NOLOG
+                    for (int k = 0; k < 4; k++) l2[k] = __log2f(l2[k]);
+#else
+                    for (int k = 0; k < 4; k++) l2[k] = l2[k] * 3.0f;
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const int e = 4 * q + k;
-                        abs2[k] = re[e] * re[e] + im[e] * im[e];                       // worker.js:92
-                        mn = min_nn(mn, abs2[k]);
-                        mx = max_nn(mx, abs2[k]);
-                        const float l2 = __log2f((float)abs2[k]);
-                        tg[k] = __builtin_amdgcn_fmed3f(fmaf(g_b, l2, g_a), g_lo, g_hi);
-                        tc[k] = __builtin_amdgcn_fmed3f(fmaf(c_b, l2, c_a), c_lo, c_hi);
+#ifndef SP_ABL_NOMM
+                        mn4[k] = min_raw(mn4[k], abs2[k]);
+                        mx4[k] = max_raw(mx4[k], abs2[k]);
+#endif
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        tg[k] = fmaf(g_b, l2[k], g_a);
+                        tc[k] = fmaf(c_b, l2[k], c_a);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        tg[k] = __builtin_amdgcn_fmed3f(tg[k], g_lo, g_hi);
+                        tc[k] = __builtin_amdgcn_fmed3f(tc[k], c_lo, c_hi);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
                         gi[k] = floor_to_int(tg[k]);                                   // colour index
-                        cell[k] = gi[k] + floor_to_int(tc[k]);                         // + level (= 999 - centi-bel bin)
+                        cell[k] = floor_to_int(tc[k]);                                 // level (= 999 - centi-bel bin)
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#ifndef SP_ABL_NORISKY
                         risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < g_thr) || !(__builtin_amdgcn_fractf(tc[k]) < c_thr);
+#else
+                        risky[k] = false;
+#endif
+                        cell[k] += gi[k];
                     }
                     if (__builtin_expect(__ballot(risky[0] || risky[1] || risky[2] || risky[3]) != 0ull, 0)) {
 #ifdef SP_STAMPS
                         stamp_slow++;
 #endif
+                        // nearest edge on either scale for every lane (one batch of reads, one wait), then one exact comparison
+                        // each; only the risky lanes keep the result (edges: sp_host.h Thresholds)
+                        int rg[4], rc[4];
+                        double eg[4], ec[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            if (risky[k]) {
-                                // nearest edge on either scale, then one exact comparison each (edges: sp_host.h Thresholds)
-                                int rg = (int)rintf(tg[k] + g_m);
-                                rg = rg < 1 ? 1 : (rg > cmax ? cmax : rg);
-                                int rc = (int)rintf(tc[k] + c_m);
-                                rc = rc < 1 ? 1 : (rc > SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE : rc);
-                                const double eg = edge_g[rg], ec = edge_cb[rc];
-                                int g = abs2[k] >= eg ? rg : rg - 1;
-                                int c = g + (abs2[k] >= ec ? rc : rc - 1);
-                                // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
-                                if (!(abs2[k] > 0.0)) {
-                                    g = 0;
-                                    c = cell_sp0;
-                                } else if (abs2[k] == spjs::inf()) {
-                                    c = cell_sp0 + 1;
-                                }
-                                gi[k] = g;
-                                cell[k] = c;
+                            rg[k] = min(max((int)rintf(tg[k] + g_m), 1), cmax);
+                            rc[k] = min(max((int)rintf(tc[k] + c_m), 1), SP_CB_HIST_SIZE);
+                            eg[k] = edge_g[rg[k]];
+                            ec[k] = edge_cb[rc[k]];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            int g = abs2[k] >= eg[k] ? rg[k] : rg[k] - 1;
+                            int c = g + (abs2[k] >= ec[k] ? rc[k] : rc[k] - 1);
+                            // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
+                            if (!(abs2[k] > 0.0)) {
+                                g = 0;
+                                c = cell_sp0;
+                            } else if (abs2[k] == spjs::inf()) {
+                                c = cell_sp0 + 1;
                             }
+                            gi[k] = risky[k] ? g : gi[k];
+                            cell[k] = risky[k] ? c : cell[k];
                         }
                     }
 #ifndef SP_ABL_NOTILE
@@ -659,6 +709,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #endif
                     }
                 }
+                const double mn = min_raw(min_raw(mn4[0], mn4[1]), min_raw(mn4[2], mn4[3]));
+                const double mx = max_raw(max_raw(mx4[0], mx4[1]), max_raw(mx4[2], mx4[3]));
                 unsigned long long *slot = s_mm + 2 * (fr * MMS + (tl & (MMS - 1)));
                 atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
