@@ -11,6 +11,8 @@
  *   sp_format_parse          lib/samples.js:22-162      the format-name table (aliases, unknown -> CU8)
  *   sp_slice_bounds          lib/samples.js:253-258     SampleView.slice: the caller's per-worker byte range
  *   sp_window                lib/windows.js:14-88       named taper generators (optional sugar; the wire carries arrays)
+ *   sp_cmap, sp_cmap_key     lib/cube1cmap.js, lib/matplotlibcmaps.js, lib/soxcmap.js, lib/naivecmap.js, lib/utils.js:25-40
+ *   sp_render_named          lib/spectroplot.js:1113-1146, 1213-1226   the caller's message assembly from option names
  *   sp_twiddles              lib/fft_nayuki.js:42-47    cos/sin tables (exposed for tests)
  *   sp_plan_create           lib/worker.js:30-62        per-request constants + the cached FFT object
  *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
@@ -105,6 +107,17 @@ int sp_format_element_size(int32_t format);
 int sp_slice_bounds(size_t nbytes, int32_t sample_width, int32_t index, int32_t count, size_t *begin, size_t *end);
 /* Named tapers: "rectangular", "bartlett", "hamming", "hann", "blackman", "blackmanHarris" (exact names). */
 int sp_window(const char *name, int32_t n, double *window, double *weight);
+/*
+ * Colour maps of the reference under its own keys ("cube1_cmap", "sox_cmap", ... "viridis_cmap", "parabola_cmap"), in the key
+ * order of its merged table (lib/spectroplot.js:41).  sp_cmap resolves `name` as lib/utils.js:25-40 does (exact, then
+ * case-insensitive, then case-insensitive prefix, first hit in key order) and copies the r,g,b triples as the reference's
+ * modules evaluate them, i.e. BEFORE the caller's end forcing (lib/spectroplot.js:1129-1130).  *lut_len receives the entry count
+ * (also when rgb is NULL or capacity_entries is too small, which returns SP_ERR_INVALID_ARG); an unknown name returns
+ * SP_ERR_UNSUPPORTED.
+ */
+int sp_cmap_count(void);
+const char *sp_cmap_key(int32_t index);
+int sp_cmap(const char *name, uint8_t *rgb, int32_t capacity_entries, int32_t *lut_len);
 /* cosTable / sinTable of the reference's FFT object, n/2 entries each. */
 int sp_twiddles(int32_t n, double *cos_table, double *sin_table);
 /* The engine's Math.log10 as restated by this library (exposed so tests can pin it). */
@@ -127,6 +140,22 @@ int sp_context_synchronize(sp_context *ctx);
  */
 int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
 
+/*
+ * The same with the request given by names, as the reference's caller assembles its message from options
+ * (lib/spectroplot.js:1113-1146): window = lookup(windows, name) or blackmanHarris, block_norm = 1 / weight, cmap = lookup or
+ * cube1 with its ends forced to black / white, format by sp_format_parse.  The plan (and its device tables) is kept while the
+ * names and numbers repeat: nothing is re-evaluated or re-uploaded then.
+ */
+typedef struct sp_named_request {
+    const char *format;      /* "cu8", "CF32", ... (unknown -> CU8, as the reference) */
+    const char *window;      /* "hann", "blackmanHarris", ... (lookup rules of lib/utils.js:25-40; no hit -> blackmanHarris) */
+    const char *cmap;        /* "viridis", "cube1_cmap", ... (same lookup; no hit -> cube1) */
+    int32_t n;
+    int32_t channel_mode, waterfall;
+    double gain, range;
+} sp_named_request;
+int sp_render_named(sp_context *ctx, const sp_named_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+
 /* Pre-evaluated request constants resident on the device: twiddles, taper, RGBA LUT, threshold tables. */
 int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **plan);
 void sp_plan_destroy(sp_plan *plan);
@@ -145,10 +174,17 @@ int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t w
  */
 int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int32_t lut_len, uint64_t *d_c_hist, uint64_t *d_cb_hist,
                      double *d_dbfs_minmax);
-/* Name of the kernel variant sp_plan_execute launches ("lds_r16", "scratch_radix2"). */
+/* Name of the kernel variant sp_plan_execute launches ("frames", "lds_r16", "scratch_radix2"). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
-/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16. */
+/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16, 3 frames. */
 int sp_plan_force_kernel(sp_plan *plan, int32_t which);
+
+/*
+ * Page-locked host memory for request / reply buffers: sp_render moves pinned buffers at the full rate of the host link, pageable
+ * ones through the runtime's staging copies.  The N-API addon backs the reply ArrayBuffers it hands out with these.
+ */
+int sp_host_alloc(size_t nbytes, void **ptr);
+void sp_host_free(void *ptr);
 
 /* Device memory helpers so that non-HIP hosts (Node, ctypes) can keep operands resident. */
 int sp_device_alloc(sp_context *ctx, size_t nbytes, void **d_ptr);

@@ -19,6 +19,7 @@
 #include "sp_kernel_frames.h"
 #include "sp_kernel_scratch.h"
 #include "sp_synth.h"
+#include "sp_cmap_tables.h"
 
 namespace {
 
@@ -62,6 +63,13 @@ struct sp_context {
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small;
     sp_plan *cached_plan = nullptr;
+    // sp_render_named: the names and numbers the cached plan was built from (empty: the cached plan came from arrays)
+    std::string named_format, named_window, named_cmap;
+    int32_t named_n = 0, named_ch = 0, named_wf = 0;
+    double named_gain = 0, named_range = 0;
+    std::vector<double> named_windowc;
+    std::vector<uint8_t> named_lut;
+    double named_block_norm = 0;
     bool acc_dirty = false;      // a request failed between its two kernels: accumulators must be re-initialised
     int cell_toggle = 0;         // which of the two merged-cell buffers the next k_frames launch counts into
     // timing
@@ -199,6 +207,42 @@ extern "C" int sp_twiddles(int32_t n, double *cos_table, double *sin_table)
 }
 
 extern "C" double sp_js_log10(double x) { return spjs::log10(x); }
+
+extern "C" int sp_cmap_count(void) { return spcmap::kCount; }
+
+extern "C" const char *sp_cmap_key(int32_t index) { return index >= 0 && index < spcmap::kCount ? spcmap::kEntries[index].key : ""; }
+
+static int cmap_index(const char *name)
+{
+    const char *keys[spcmap::kCount];
+    for (int i = 0; i < spcmap::kCount; i++) keys[i] = spcmap::kEntries[i].key;
+    return sphost::lookup_key(keys, spcmap::kCount, name);
+}
+
+extern "C" int sp_cmap(const char *name, uint8_t *rgb, int32_t capacity_entries, int32_t *lut_len)
+{
+    const int i = cmap_index(name);
+    if (i < 0) return SP_ERR_UNSUPPORTED;
+    const spcmap::Entry &e = spcmap::kEntries[i];
+    if (lut_len) *lut_len = e.length;
+    if (!rgb || capacity_entries < e.length) return SP_ERR_INVALID_ARG;
+    memcpy(rgb, spcmap::kData + e.offset, 3 * (size_t)e.length);
+    return SP_OK;
+}
+
+extern "C" int sp_host_alloc(size_t nbytes, void **ptr)
+{
+    if (!ptr) return SP_ERR_INVALID_ARG;
+    *ptr = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return SP_ERR_NO_DEVICE;
+    return hipHostMalloc(ptr, nbytes ? nbytes : 1, hipHostMallocDefault) == hipSuccess ? SP_OK : SP_ERR_NOMEM;
+}
+
+extern "C" void sp_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
 
 // ------------------------------------------------------------------------------------------------- contexts
 
@@ -853,4 +897,57 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return hip_fail(ctx, e, "sp_render download");
     return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- requests by name
+
+extern "C" int sp_render_named(sp_context *ctx, const sp_named_request *nr, const uint8_t *bytes, size_t nbytes, int32_t width,
+                               const sp_reply *reply)
+{
+    if (!ctx || !nr || !reply) return SP_ERR_INVALID_ARG;
+    if (nr->n < 1 || sphost::log2_exact(nr->n) < 0) return fail(ctx, SP_ERR_NOT_POW2, "Length is not a power of 2");
+    if (nr->n > SP_MAX_N) return fail(ctx, SP_ERR_UNSUPPORTED, "n exceeds SP_MAX_N");
+    const std::string f = nr->format ? nr->format : "", w = nr->window ? nr->window : "", c = nr->cmap ? nr->cmap : "";
+    const bool same = ctx->cached_plan && !ctx->named_windowc.empty() && ctx->named_format == f && ctx->named_window == w && ctx->named_cmap == c
+                      && ctx->named_n == nr->n && ctx->named_ch == (nr->channel_mode ? 1 : 0) && ctx->named_wf == (nr->waterfall ? 1 : 0)
+                      && !memcmp(&ctx->named_gain, &nr->gain, 8) && !memcmp(&ctx->named_range, &nr->range, 8);
+    if (!same) {
+        // the caller's message assembly (lib/spectroplot.js:1113-1146)
+        ctx->named_windowc.assign((size_t)nr->n, 0.0);
+        double weight = 0.0;
+        if (!sphost::window(sphost::window_by_name(w.c_str()), nr->n, ctx->named_windowc.data(), &weight))
+            return fail(ctx, SP_ERR_INVALID_ARG, "window");
+        ctx->named_block_norm = 1.0 / weight;
+        int ci = cmap_index(c.c_str());
+        if (ci < 0) ci = 0;                                              // cube1 (lib/spectroplot.js:252-264)
+        const spcmap::Entry &e = spcmap::kEntries[ci];
+        ctx->named_lut.assign(spcmap::kData + e.offset, spcmap::kData + e.offset + 3 * (size_t)e.length);
+        for (int k = 0; k < 3; k++) {                                    // ends forced to black / white (:1129-1130)
+            ctx->named_lut[(size_t)k] = 0;
+            ctx->named_lut[3 * (size_t)(e.length - 1) + (size_t)k] = 255;
+        }
+        ctx->named_format = f;
+        ctx->named_window = w;
+        ctx->named_cmap = c;
+        ctx->named_n = nr->n;
+        ctx->named_ch = nr->channel_mode ? 1 : 0;
+        ctx->named_wf = nr->waterfall ? 1 : 0;
+        ctx->named_gain = nr->gain;
+        ctx->named_range = nr->range;
+    }
+    sp_request r{};
+    r.format = sphost::parse_format(f.c_str());
+    r.n = nr->n;
+    r.channel_mode = nr->channel_mode;
+    r.waterfall = nr->waterfall;
+    r.lut_len = (int32_t)(ctx->named_lut.size() / 3);
+    r.block_norm = ctx->named_block_norm;
+    r.gain = nr->gain;
+    r.range = nr->range;
+    r.windowc = ctx->named_windowc.data();
+    r.lut_rgb = ctx->named_lut.data();
+    // same names and numbers: sp_render finds the cached plan by value (same arrays), nothing is rebuilt or uploaded
+    const int rc = sp_render(ctx, &r, bytes, nbytes, width, reply);
+    if (rc) ctx->named_windowc.clear();
+    return rc;
 }

@@ -78,6 +78,33 @@ bool window(const char *name, int32_t n, double *out, double *weight)
     return true;
 }
 
+int32_t lookup_key(const char *const *keys, int32_t count, const char *name)
+{
+    if (!name || !*name) return -1;
+    for (int32_t i = 0; i < count; i++)
+        if (!strcmp(keys[i], name)) return i;
+    auto lower_eq = [](const char *key, const char *want, bool prefix) {
+        size_t i = 0;
+        for (; want[i]; i++)
+            if (!key[i] || tolower((unsigned char)key[i]) != tolower((unsigned char)want[i])) return false;
+        return prefix || key[i] == 0;
+    };
+    for (int32_t i = 0; i < count; i++)
+        if (lower_eq(keys[i], name, false)) return i;
+    for (int32_t i = 0; i < count; i++)
+        if (lower_eq(keys[i], name, true)) return i;
+    return -1;
+}
+
+const char *window_by_name(const char *name)
+{
+    // key order of the reference's `windows` module namespace (sorted; tests/golden/parse.json window_key_order)
+    static const char *const keys[] = {"bartlettWindow", "blackmanHarrisWindow", "blackmanWindow", "hammingWindow", "hannWindow", "rectangularWindow"};
+    static const char *const plain[] = {"bartlett", "blackmanHarris", "blackman", "hamming", "hann", "rectangular"};
+    const int32_t i = lookup_key(keys, 6, name);
+    return plain[i < 0 ? 1 : i];
+}
+
 PixelMath::PixelMath(double block_norm, double gain_, double range_, int32_t lut_len)
     : block_norm_db(10 * spjs::log10(block_norm)), gain(gain_), range(range_), color_max((double)(lut_len - 1)),
       color_norm((double)lut_len / -range_)

@@ -22,6 +22,11 @@ void twiddles(int32_t n, double *cos_table, double *sin_table);
 // lib/windows.js:14-88; returns false for an unknown name
 bool window(const char *name, int32_t n, double *out, double *weight);
 
+// lib/utils.js:25-40 over a list of keys: exact, then case-insensitive, then case-insensitive prefix; first hit in key order, -1: none
+int32_t lookup_key(const char *const *keys, int32_t count, const char *name);
+// lookup(windows, name) || windows.blackmanHarrisWindow (lib/spectroplot.js:241): the generator's plain name ("hann", ...)
+const char *window_by_name(const char *name);
+
 // The per-pixel arithmetic of lib/worker.js:92-113 as a function of abs2 = re^2 + im^2.
 struct PixelMath {
     double block_norm_db;   // 10 * log10(block_norm)                      worker.js:31

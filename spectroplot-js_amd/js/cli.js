@@ -5,16 +5,16 @@
  * (lib/spectroplot.js:1096-1285) without a browser:
  *
  *   node spectroplot-js_amd/js/cli.js capture_433.92M_250k.cu8 --n 1024 --width 2048 [--format cu8] [--window blackmanHarris]
- *        [--cmap sox|naive|grayscale|roentgen|phosphor] [--gain 6] [--range 30] [--workers N] [--waterfall] [--lr] --out image.ppm
+ *        [--cmap cube1|viridis|plasma|inferno|magma|hot|afmhot|gist_heat|sox|naive|grayscale|roentgen|phosphor|parabola] [--gain 6] [--range 30] [--workers N] [--waterfall] [--lr] --out image.ppm
  *
  * The format defaults to the file extension (lib/parseFreqRate.js:58-70), the worker count to the number of visible GPUs.
  * Output: binary PPM (P6, alpha dropped) or, with --out *.rgba, the raw RGBA bytes exactly as the reference's canvas holds them.
  */
 const fs = require('fs')
-const { renderSliced, parseFormat, parseFreqRate, lookup, computedCmaps, windowByName, HipWorker } = require('./index.js')
+const { renderSliced, parseFormat, parseFreqRate, cmapByName, windowByName, HipWorker } = require('./index.js')
 
 function main(argv) {
-    const opt = { n: 512, width: 1024, window: 'blackmanHarris', cmap: 'sox', gain: 6, range: 30, out: 'spectrogram.ppm' }
+    const opt = { n: 512, width: 1024, window: 'blackmanHarris', cmap: 'cube1', gain: 6, range: 30, out: 'spectrogram.ppm' }
     let file = null
     for (let i = 0; i < argv.length; i++) {
         const a = argv[i]
@@ -28,7 +28,7 @@ function main(argv) {
     const buffer = bytes.buffer.slice(bytes.byteOffset, bytes.byteOffset + bytes.byteLength)
     const format = opt.format || parseFormat(file)
     const n = parseInt(opt.n, 10), width = parseInt(opt.width, 10)
-    const cmap = lookup(computedCmaps, opt.cmap) || computedCmaps.sox_cmap
+    const cmap = cmapByName(opt.cmap)
     const w = windowByName(opt.window)(n)
     const fr = parseFreqRate(file)
     const t0 = Date.now()

@@ -64,9 +64,10 @@ class HipWorker {
         if (this._closed) return
         if (!(message && message.buffer)) return                        // worker.js:159
         // requests are serialised per instance, like one worker thread; the GPU work itself runs off the event loop
-        this._queue = this._queue.then(() => this._render(message)).then(
-            reply => this._emit('message', { data: reply }),
-            err => this._emit('error', { message: err.message, status: err.status, error: err }))
+        // (a worker that has been terminated meanwhile neither starts queued requests nor reports anything)
+        this._queue = this._queue.then(() => this._closed ? null : this._render(message)).then(
+            reply => { if (reply && !this._closed) this._emit('message', { data: reply }) },
+            err => { if (!this._closed) this._emit('error', { message: err.message, status: err.status, error: err }) })
     }
 
     _request(m) {
@@ -100,11 +101,27 @@ class HipWorker {
     /** Synchronous render of one message (used by tests and by callers that drive the GPUs themselves). */
     renderSync(m) { return this._wrap(m, addon().renderSync(this._ctx, this._request(m))) }
 
-    terminate() { this._closed = true; this._ctx = null }
+    /**
+     * Worker.terminate(): queued requests are dropped, nothing is emitted any more, and the device context (stream, staging and
+     * workspace buffers) is released as soon as the render that may be running on a libuv thread has returned.
+     */
+    terminate() {
+        if (this._closed) return
+        this._closed = true
+        const ctx = this._ctx
+        this._ctx = null
+        if (ctx) addon().destroyContext(ctx)
+    }
 }
 
 /** A constructor bound to one device, for `workerOrUrl: HipWorker.onDevice(3)`. */
 HipWorker.onDevice = (device) => class extends HipWorker { constructor() { super({ device }) } }
 HipWorker.deviceCount = () => addon().deviceCount()
+/**
+ * An ArrayBuffer in page-locked host memory.  A message whose `buffer` is one of these is copied to the GPU at the full rate of
+ * the host link (pageable memory goes through the runtime's staging copies at less than half of it); js/render_file.js cuts its
+ * slices into such buffers, where the reference's SampleView.slice copies into a plain one (lib/samples.js:253-258).
+ */
+HipWorker.allocBuffer = (nbytes) => addon().allocBuffer(nbytes)
 
 module.exports = { HipWorker, packLut }

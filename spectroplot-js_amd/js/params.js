@@ -1,26 +1,33 @@
 'use strict'
 /**
  * Parameter helpers on the caller's side of the worker message — the "next" rows of SURVEY.md §8(f):
- *   lookup            lib/utils.js:25-40        exact -> case-insensitive -> prefix key match
- *   windowByName      lib/windows.js:14-88 through the C ABI (sp_window, bit-identical tapers)
- *   computed LUTs     lib/soxcmap.js:12-49, lib/naivecmap.js:13-81 (sox, naive, grayscale, roentgen, phosphor)
- *   parseFormat       lib/parseFreqRate.js:58-70   file name -> FORMAT string
- *   parseFreqRate     lib/parseFreqRate.js:16-55   file name -> {freq, rate}
- * The table-defined colour maps of the reference (viridis, cube1, ...) are data files of that project and are not
- * reproduced here; pass them as arrays, exactly as the worker message carries them.
+ *   lookup          key resolution of the reference's option tables (lib/utils.js:25-40)
+ *   windows         the reference's `windows` module as a table of generators, evaluated by the native library (sp_window,
+ *                   bit-identical to lib/windows.js:14-88)
+ *   cmaps           the reference's merged colour-map table (lib/spectroplot.js:41), served by the native library (sp_cmap):
+ *                   every map as the reference's modules evaluate it, under the reference's keys and key order
+ *   parseFormat     file name -> FORMAT string (lib/parseFreqRate.js:58-70)
+ *   parseFreqRate   file name -> {freq, rate} (lib/parseFreqRate.js:16-55)
  */
 const path = require('path')
 
 function addon() { return require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node')) }
 
-/** Returns table[key] for an exact, then case-insensitive, then prefix match; non-strings pass through. */
-function lookup(table, arrayOrKey) {
-    if (!arrayOrKey || typeof arrayOrKey !== 'string') return arrayOrKey
-    if (table[arrayOrKey]) return table[arrayOrKey]
-    const want = arrayOrKey.toLowerCase()
+// The three match grades of the reference's lookup, strongest first; a key wins by grade, then by table order.
+const MATCH_GRADES = [
+    (key, want) => key === want,
+    (key, want) => key.toLowerCase() === want.toLowerCase(),
+    (key, want) => key.toLowerCase().startsWith(want.toLowerCase()),
+]
+
+/** table[key] for the best-matching key (exact > same letters > prefix); anything that is not a non-empty string passes through. */
+function lookup(table, nameOrValue) {
+    if (typeof nameOrValue !== 'string' || nameOrValue === '') return nameOrValue
     const keys = Object.keys(table)
-    for (const k of keys) if (k.toLowerCase() === want) return table[k]
-    for (const k of keys) if (k.toLowerCase().startsWith(want)) return table[k]
+    for (const grade of MATCH_GRADES) {
+        const hit = keys.find(key => grade(key, nameOrValue))
+        if (hit !== undefined && table[hit]) return table[hit]
+    }
     return null
 }
 
@@ -35,90 +42,71 @@ for (const name of WINDOW_NAMES) {
 /** `lookup(windows, value) || windows.blackmanHarrisWindow` (lib/spectroplot.js:241) */
 function windowByName(value) { return lookup(windows, value) || windows.blackmanHarrisWindow }
 
-function soxCmap(stops) {
-    stops = stops || 256
-    const out = []
-    for (let i = 0; i < stops; ++i) {
-        const x = i / (stops - 1.0)
-        const r = x < .13 ? 0 : x < .73 ? 1 * Math.sin((x - .13) / .60 * Math.PI / 2) : 1
-        const g = x < .60 ? 0 : x < .91 ? 1 * Math.sin((x - .60) / .31 * Math.PI / 2) : 1
-        const b = x < .60 ? .5 * Math.sin((x - .00) / .60 * Math.PI) : x < .78 ? 0 : (x - .78) / .22
-        out.push([Math.round(255 * r), Math.round(255 * g), Math.round(255 * b)])
-    }
-    return out
-}
-
-function naiveCmap(stops) {
-    stops = stops || 256
-    const out = []
-    for (let i = 0; i < stops; ++i) {
-        let r, g, b
-        if (i < stops / 4) { b = i * 128 / (stops / 4); g = 0; r = 0 } else if (i < stops / 2) { b = 256 - i / 2; g = 0; r = i - stops / 4 } else if (i < stops * 3 / 4) { b = 0; g = i - stops / 2; r = 255 } else { b = i - stops * 3 / 4; g = 255; r = 255 }
-        out.push([~~r, ~~g, ~~b])
-    }
-    return out
-}
-
-function grayscaleCmap(stops) {
-    stops = stops || 256
-    const out = []
-    for (let i = 0; i < stops; ++i) { const c = ~~(i * 255 / stops); out.push([c, c, c]) }
-    return out
-}
-
-function roentgenCmap(stops) {
-    stops = stops || 256
-    const out = []
-    for (let i = 0; i < stops; ++i) { const c = ~~(255 - (i * 255 / stops)); out.push([c, c, c]) }
-    return out
-}
-
-function phosphorCmap(stops) {
-    stops = stops || 256
-    const out = []
-    for (let i = 0; i < stops; ++i) {
-        let r, g, b
-        if (i < stops / 2) { r = 0; g = i * 191 / (stops / 2); b = 0 } else {
-            r = (i - stops / 2) * 255 / (stops / 2); g = 191 + (i - stops / 2) * 64 / (stops / 2); b = (i - stops / 2) * 255 / (stops / 2)
-        }
-        out.push([~~r, ~~g, ~~b])
-    }
-    return out
-}
-
-/** The computed colour maps under the reference's key names (…_cmap); extend with your own tables and use `lookup`. */
-const computedCmaps = {
-    sox_cmap: soxCmap(), grayscale_cmap: grayscaleCmap(), naive_cmap: naiveCmap(), phosphor_cmap: phosphorCmap(), roentgen_cmap: roentgenCmap(),
-}
-/** Key order of the reference's merged colour-map table (lib/spectroplot.js:41), for callers that add the table-defined maps. */
+/** Key order of the reference's merged colour-map table. */
 const CMAP_KEY_ORDER = ['cube1_cmap', 'sox_cmap', 'grayscale_cmap', 'naive_cmap', 'phosphor_cmap', 'roentgen_cmap', 'afmhot_cmap', 'gist_heat_cmap',
     'hot_cmap', 'inferno_cmap', 'magma_cmap', 'plasma_cmap', 'viridis_cmap', 'parabola_cmap']
 
-/** File name -> upper-cased extension, '?' without one (lib/parseFreqRate.js:58-70). */
-function parseFormat(name) {
-    if (!name || typeof name !== 'string') return '?'
-    const pos = name.lastIndexOf('.')
-    return pos !== -1 ? name.substr(pos + 1).toUpperCase() : '?'
+/** One colour map as the worker message carries it: an array of [r, g, b] (ends not forced yet). */
+function cmapEntries(key) {
+    const flat = addon().cmap(key)
+    if (!flat) return null
+    const out = new Array(flat.length / 3)
+    for (let i = 0; i < out.length; i++) out[i] = [flat[3 * i], flat[3 * i + 1], flat[3 * i + 2]]
+    return out
 }
 
-/** File name -> {freq, rate}: numbers after a separator [-_ .], suffixed M -> centre frequency, k -> sample rate. */
+/** The merged colour-map table; maps are fetched from the native library on first use. */
+const cmaps = {}
+for (const key of CMAP_KEY_ORDER) {
+    Object.defineProperty(cmaps, key, {
+        enumerable: true, configurable: true,
+        get() { const v = cmapEntries(key); Object.defineProperty(cmaps, key, { value: v, enumerable: true }); return v },
+    })
+}
+/** `lookup(cmaps, value) || cmaps.cube1_cmap` (lib/spectroplot.js:252-264) */
+function cmapByName(value) { return lookup(cmaps, value) || cmaps.cube1_cmap }
+
+/** File name -> the text after its last dot, upper-cased; '?' when there is no dot or no name. */
+function parseFormat(name) {
+    const m = typeof name === 'string' ? /\.([^.]*)$/.exec(name) : null
+    return m ? m[1].toUpperCase() : '?'
+}
+
+const SEPARATOR = /[-_ .]/g
+const DIGITS_AND_DOTS = /[0-9.]*/y
+/**
+ * Number tokens of a file name as the reference reads them: a separator, then whatever parseFloat accepts; the character behind the
+ * number's digits and dots is its unit.  Characters are consumed left to right: the character behind a separator that starts no
+ * number is skipped with it, and so is every unit character (so neither can act as a separator itself), and the last character
+ * of the name never starts a token.
+ */
+function* numberTokens(name) {
+    let pos = 0
+    while (pos < name.length - 1) {
+        SEPARATOR.lastIndex = pos
+        const sep = SEPARATOR.exec(name)
+        if (!sep || sep.index >= name.length - 1) return
+        const start = sep.index + 1
+        const value = parseFloat(name.slice(start))
+        if (Number.isNaN(value)) { pos = start + 1; continue }
+        DIGITS_AND_DOTS.lastIndex = start
+        DIGITS_AND_DOTS.exec(name)
+        const unitAt = DIGITS_AND_DOTS.lastIndex
+        yield { value, unit: name[unitAt] }
+        pos = unitAt + 1
+    }
+}
+
+/** File name -> {freq, rate}: the last number with unit M (MHz) is the centre frequency, the last with unit k (kHz) the sample rate. */
 function parseFreqRate(name) {
     if (!name || typeof name !== 'string') return { freq: 0, rate: 0 }
-    const slash = name.lastIndexOf('/')
-    if (slash !== -1) name = name.substr(slash + 1)
-    let freq = 0, rate = 1
-    for (let p = 0; p < name.length - 1; ++p) {
-        const ch = name[p]
-        if (ch !== '_' && ch !== '-' && ch !== ' ' && ch !== '.') continue
-        ++p
-        const f = parseFloat(name.substr(p))
-        if (isNaN(f)) continue
-        while (p < name.length && ((name[p] >= '0' && name[p] <= '9') || name[p] === '.')) ++p
-        if (name[p] === 'M' || name[p] === 'm') freq = f * 1000000.0
-        if (name[p] === 'k' || name[p] === 'K') rate = f * 1000.0
+    const base = name.slice(name.lastIndexOf('/') + 1)
+    const found = { freq: 0, rate: 1 }
+    for (const { value, unit } of numberTokens(base)) {
+        if (unit === 'M' || unit === 'm') found.freq = value * 1000000.0
+        if (unit === 'k' || unit === 'K') found.rate = value * 1000.0
     }
-    return { freq, rate }
+    return found
 }
 
-module.exports = { lookup, windows, windowByName, computedCmaps, CMAP_KEY_ORDER, soxCmap, naiveCmap, grayscaleCmap, roentgenCmap, phosphorCmap, parseFormat,
-    parseFreqRate }
+module.exports = { lookup, windows, windowByName, cmaps, cmapByName, cmapEntries, CMAP_KEY_ORDER, parseFormat, parseFreqRate }

@@ -41,8 +41,12 @@ function renderSliced(o, pool) {
     const jobs = []
     for (let i = 0; i < workers; i++) {
         const [b0, b1] = a.sliceBounds(o.buffer.byteLength, fmt.sampleWidth, i, workers)
+        // the slice is a copy, as in the reference (SampleView.slice -> ArrayBuffer.slice); here it lands in page-locked memory,
+        // from where the GPU fetches it at the full rate of the host link
+        const slice = a.allocBuffer(b1 - b0)
+        new Uint8Array(slice).set(new Uint8Array(o.buffer, b0, b1 - b0))
         const message = { block_norm, gain, range, cmap, n, windowc: w.window, width: sliceWidth, offset: i * sliceWidth,
-            buffer: o.buffer.slice(b0, b1), format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+            buffer: slice, format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
         const k = i % pool.length
         jobs.push(new Promise((resolve, reject) => {
             pending[k].push({ resolve, reject })

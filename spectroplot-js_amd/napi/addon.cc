@@ -10,8 +10,12 @@
 //   parseFormat(name)                              -> {id, sampleWidth}
 //   window(name, n)                                -> {window: Float64Array, weight}
 //   sliceBounds(nbytes, sampleWidth, index, count) -> [begin, end]
+//   cmap(name)                                     -> Uint8Array of r,g,b triples (the reference's map under its lookup rules) or null
+//   cmapKeys()                                     -> the reference's colour-map keys in its table order
+//   allocBuffer(nbytes)                            -> ArrayBuffer in page-locked host memory (sp_host_alloc): a request whose `buffer`
+//                                                     is one of these goes to the device at the full rate of the host link
 //   createContext(device)                          -> external handle
-//   destroyContext(handle)
+//   destroyContext(handle)                         -> releases the device context as soon as no render is in flight on it
 //   render(handle, req, cb)   req = {format:int, buffer:ArrayBuffer, n, windowc:Float64Array, block_norm, gain, range,
 //                                    lut:Uint8Array, width, channelMode, waterfall}
 //       runs sp_render on a libuv worker thread and calls cb(err, {rgba, gauge_mins, gauge_maxs, gauge_amps: ArrayBuffer,
@@ -22,6 +26,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <sys/mman.h>
 #include <string>
 #include <vector>
 
@@ -70,7 +76,82 @@ bool get_bool(napi_env env, napi_value obj, const char *name)
     return r;
 }
 
+// One device context as JavaScript sees it.  Renders run on libuv worker threads, so the sp_context must outlive every job that
+// was queued on it: jobs count themselves in `inflight` (main thread only), destroyContext / the finalizer only mark the
+// context closed, and whoever brings the count to zero on a closed context destroys it.
+struct Ctx {
+    sp_context *c = nullptr;
+    int inflight = 0;
+    bool closed = false;
+    bool collected = false;   // the JS handle is gone: the struct itself may be deleted
+};
+
+void ctx_release(Ctx *x)
+{
+    if (x->closed && x->inflight == 0 && x->c) {
+        sp_context_destroy(x->c);
+        x->c = nullptr;
+    }
+    if (x->collected && x->inflight == 0) delete x;
+}
+
+// Image buffers of replies are recycled: a block that JavaScript has dropped (its ArrayBuffer was collected) serves a later reply
+// of the same size.  Fresh memory is the slow part of a reply (the kernel zero-fills every page the copy from the device touches
+// for the first time); a recycled block takes the copy at the rate of the host link.  V8 is told the size of every block it
+// holds (napi_adjust_external_memory), so dropped replies are collected under memory pressure like any large ArrayBuffer.
+struct HostPool {
+    struct Block { void *p; size_t size; };
+    std::mutex m;
+    std::vector<Block> free_blocks;
+    size_t free_bytes = 0;
+    static constexpr size_t kKeepBytes = (size_t)3 << 30;
+    void *take(size_t size)
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].size == size) {
+                    void *p = free_blocks[i].p;
+                    free_bytes -= size;
+                    free_blocks.erase(free_blocks.begin() + (long)i);
+                    return p;
+                }
+        }
+        // large blocks on 2 MiB boundaries with transparent huge pages requested: the first touch of a fresh block then costs one
+        // fault per 2 MiB instead of one per 4 KiB
+        void *p = nullptr;
+        const size_t align = size >= ((size_t)4 << 20) ? ((size_t)2 << 20) : 4096;
+        if (posix_memalign(&p, align, size ? size : 1) != 0) return nullptr;
+#ifdef MADV_HUGEPAGE
+        if (align > 4096) (void)madvise(p, size, MADV_HUGEPAGE);
+#endif
+        return p;
+    }
+    void give(void *p, size_t size)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (free_bytes + size > kKeepBytes) {
+            free(p);
+            return;
+        }
+        free_blocks.push_back({p, size});
+        free_bytes += size;
+    }
+};
+HostPool g_pool;
+
+struct PoolTag { size_t size; };
+void pool_free_cb(napi_env env, void *data, void *hint)
+{
+    PoolTag *t = (PoolTag *)hint;
+    int64_t total = 0;
+    napi_adjust_external_memory(env, -(int64_t)t->size, &total);
+    g_pool.give(data, t->size);
+    delete t;
+}
+
 struct Job {
+    Ctx *owner = nullptr;
     sp_context *ctx = nullptr;
     sp_request req{};
     std::vector<double> window;
@@ -78,15 +159,16 @@ struct Job {
     const uint8_t *bytes = nullptr;
     size_t nbytes = 0;
     int32_t width = 0;
-    // outputs (malloc'd, handed to JS as external ArrayBuffers)
+    // outputs: the image in a recycled block, the gauges malloc'd; handed to JS as external ArrayBuffers
     uint8_t *rgba = nullptr, *gmin = nullptr, *gmax = nullptr, *gamp = nullptr;
+    size_t rgba_size = 0;
     std::vector<uint64_t> c_hist, cb_hist;
     double minmax[2] = {0.0, -200.0};
     int status = SP_OK;
     std::string error;
     // async plumbing
     napi_async_work work = nullptr;
-    napi_ref cb_ref = nullptr, buf_ref = nullptr;
+    napi_ref cb_ref = nullptr, buf_ref = nullptr, ctx_ref = nullptr;
 };
 
 void free_cb(napi_env, void *data, void *) { free(data); }
@@ -98,7 +180,12 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
         napi_throw_type_error(env, nullptr, "context handle expected");
         return false;
     }
-    j->ctx = (sp_context *)p;
+    j->owner = (Ctx *)p;
+    if (j->owner->closed || !j->owner->c) {
+        napi_throw_error(env, nullptr, "context has been destroyed");
+        return false;
+    }
+    j->ctx = j->owner->c;
     napi_value v;
     int32_t i32 = 0;
     get_named(env, req, "format", &v); napi_get_value_int32(env, v, &i32); j->req.format = i32;
@@ -148,7 +235,8 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
 void run_job(Job *j)
 {
     const size_t W = j->width > 0 ? (size_t)j->width : 0, n = j->req.n > 0 ? (size_t)j->req.n : 0;
-    j->rgba = (uint8_t *)calloc(4 * W * n + 1, 1);
+    j->rgba_size = 4 * W * n + 1;
+    j->rgba = (uint8_t *)g_pool.take(j->rgba_size);
     j->gmin = (uint8_t *)calloc(W + 1, 1);
     j->gmax = (uint8_t *)calloc(W + 1, 1);
     j->gamp = (uint8_t *)calloc(W + 1, 1);
@@ -178,7 +266,18 @@ napi_value make_reply(napi_env env, Job *j)
             napi_set_named_property(env, out, name, ab);
         }
     };
-    put_ab("rgba", j->rgba, 4 * W * n);
+    {
+        napi_value ab;
+        PoolTag *tag = new PoolTag{j->rgba_size};
+        if (napi_create_external_arraybuffer(env, j->rgba, 4 * W * n, pool_free_cb, tag, &ab) == napi_ok) {
+            int64_t total = 0;
+            napi_adjust_external_memory(env, (int64_t)j->rgba_size, &total);
+            j->rgba = nullptr;
+            napi_set_named_property(env, out, "rgba", ab);
+        } else {
+            delete tag;
+        }
+    }
     put_ab("gauge_mins", j->gmin, W);
     put_ab("gauge_maxs", j->gmax, W);
     put_ab("gauge_amps", j->gamp, W);
@@ -199,7 +298,9 @@ napi_value make_reply(napi_env env, Job *j)
 
 void free_job(napi_env env, Job *j)
 {
-    free(j->rgba); free(j->gmin); free(j->gmax); free(j->gamp);
+    if (j->rgba) g_pool.give(j->rgba, j->rgba_size);
+    free(j->gmin); free(j->gmax); free(j->gamp);
+    if (j->ctx_ref) napi_delete_reference(env, j->ctx_ref);
     if (j->cb_ref) napi_delete_reference(env, j->cb_ref);
     if (j->buf_ref) napi_delete_reference(env, j->buf_ref);
     if (j->work) napi_delete_async_work(env, j->work);
@@ -224,7 +325,10 @@ napi_value RenderSync(napi_env env, napi_callback_info info)
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Job *j = new Job;
     if (!parse_request(env, argv[0], argv[1], j)) { free_job(env, j); return nullptr; }
+    j->owner->inflight++;
     run_job(j);
+    j->owner->inflight--;
+    ctx_release(j->owner);
     napi_value out = nullptr;
     if (j->status != SP_OK) napi_throw(env, make_error(env, j));
     else out = make_reply(env, j);
@@ -237,6 +341,8 @@ void exec_cb(napi_env, void *data) { run_job((Job *)data); }
 void done_cb(napi_env env, napi_status, void *data)
 {
     Job *j = (Job *)data;
+    j->owner->inflight--;
+    ctx_release(j->owner);
     napi_value cb, global, argv[2];
     napi_get_reference_value(env, j->cb_ref, &cb);
     napi_get_global(env, &global);
@@ -263,6 +369,8 @@ napi_value Render(napi_env env, napi_callback_info info)
     napi_get_named_property(env, argv[1], "buffer", &buf);
     napi_create_reference(env, buf, 1, &j->buf_ref);     // keep the input alive while the worker thread reads it
     napi_create_reference(env, argv[2], 1, &j->cb_ref);
+    napi_create_reference(env, argv[0], 1, &j->ctx_ref);   // the handle (and with it the Ctx) stays reachable while the job runs
+    j->owner->inflight++;
     napi_create_string_utf8(env, "spectroplot_hip.render", NAPI_AUTO_LENGTH, &name);
     NAPI_OK(env, napi_create_async_work(env, nullptr, name, exec_cb, done_cb, j, &j->work));
     NAPI_OK(env, napi_queue_async_work(env, j->work));
@@ -343,7 +451,95 @@ napi_value SliceBounds(napi_env env, napi_callback_info info)
     return out;
 }
 
-void ctx_finalize(napi_env, void *data, void *) { sp_context_destroy((sp_context *)data); }
+void ctx_finalize(napi_env, void *data, void *)
+{
+    Ctx *x = (Ctx *)data;
+    x->closed = true;
+    x->collected = true;
+    ctx_release(x);
+}
+
+napi_value DestroyContext(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) {
+        napi_throw_type_error(env, nullptr, "context handle expected");
+        return nullptr;
+    }
+    Ctx *x = (Ctx *)p;
+    x->closed = true;
+    ctx_release(x);
+    napi_value v;
+    napi_get_boolean(env, x->c == nullptr, &v);    // true: released now; false: a render is still in flight, released when it ends
+    return v;
+}
+
+void pinned_free_cb(napi_env env, void *data, void *hint)
+{
+    int64_t total = 0;
+    napi_adjust_external_memory(env, -(int64_t)(size_t)hint, &total);
+    sp_host_free(data);
+}
+
+napi_value AllocBuffer(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    double nbytes = 0;
+    napi_get_value_double(env, argv[0], &nbytes);
+    if (!(nbytes >= 0) || nbytes > 4e12) return throw_status(env, SP_ERR_INVALID_ARG, "allocBuffer: bad size");
+    void *p = nullptr;
+    const int rc = sp_host_alloc((size_t)nbytes, &p);
+    if (rc) return throw_status(env, rc, rc == SP_ERR_NO_DEVICE ? "no HIP device: spectroplot-hip has no CPU fallback" : "page-locked allocation failed");
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, (size_t)nbytes, pinned_free_cb, (void *)(size_t)nbytes, &ab) != napi_ok) {
+        sp_host_free(p);
+        napi_throw_error(env, nullptr, "napi_create_external_arraybuffer failed");
+        return nullptr;
+    }
+    int64_t total = 0;
+    napi_adjust_external_memory(env, (int64_t)nbytes, &total);
+    return ab;
+}
+
+napi_value Cmap(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1], sname;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    NAPI_OK(env, napi_coerce_to_string(env, argv[0], &sname));
+    char name[96];
+    size_t len = 0;
+    napi_get_value_string_utf8(env, sname, name, sizeof name, &len);
+    int32_t entries = 0;
+    napi_value out;
+    if (sp_cmap(name, nullptr, 0, &entries) == SP_ERR_UNSUPPORTED) {
+        napi_get_null(env, &out);
+        return out;
+    }
+    napi_value ab;
+    void *data;
+    NAPI_OK(env, napi_create_arraybuffer(env, 3 * (size_t)entries, &data, &ab));
+    sp_cmap(name, (uint8_t *)data, entries, &entries);
+    NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, 3 * (size_t)entries, ab, 0, &out));
+    return out;
+}
+
+napi_value CmapKeys(napi_env env, napi_callback_info)
+{
+    napi_value out, v;
+    const int n = sp_cmap_count();
+    napi_create_array_with_length(env, (size_t)n, &out);
+    for (int i = 0; i < n; i++) {
+        napi_create_string_utf8(env, sp_cmap_key(i), NAPI_AUTO_LENGTH, &v);
+        napi_set_element(env, out, (uint32_t)i, v);
+    }
+    return out;
+}
 
 napi_value CreateContext(napi_env env, napi_callback_info info)
 {
@@ -355,8 +551,15 @@ napi_value CreateContext(napi_env env, napi_callback_info info)
     sp_context *ctx = nullptr;
     const int rc = sp_context_create(dev, &ctx);
     if (rc) return throw_status(env, rc, rc == SP_ERR_NO_DEVICE ? "no HIP device: spectroplot-hip has no CPU fallback" : nullptr);
+    Ctx *x = new Ctx;
+    x->c = ctx;
     napi_value ext;
-    NAPI_OK(env, napi_create_external(env, ctx, ctx_finalize, nullptr, &ext));
+    if (napi_create_external(env, x, ctx_finalize, nullptr, &ext) != napi_ok) {
+        sp_context_destroy(ctx);
+        delete x;
+        napi_throw_error(env, nullptr, "napi_create_external failed");
+        return nullptr;
+    }
     return ext;
 }
 
@@ -368,6 +571,10 @@ napi_value Init(napi_env env, napi_value exports)
         {"window", nullptr, Window, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"sliceBounds", nullptr, SliceBounds, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"createContext", nullptr, CreateContext, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"destroyContext", nullptr, DestroyContext, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"allocBuffer", nullptr, AllocBuffer, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"cmap", nullptr, Cmap, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"cmapKeys", nullptr, CmapKeys, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"renderSync", nullptr, RenderSync, nullptr, nullptr, nullptr, napi_default, nullptr},
     };

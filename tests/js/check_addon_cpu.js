@@ -8,7 +8,7 @@ const G = require('./golden_util.js')
 const addon = require('../../spectroplot-js_amd/lib/spectroplot_hip.node')
 const { HipWorker, packLut } = require('../../spectroplot-js_amd/js')
 
-for (const k of ['deviceCount', 'parseFormat', 'window', 'sliceBounds', 'createContext', 'render', 'renderSync']) assert.strictEqual(typeof addon[k], 'function', k)
+for (const k of ['deviceCount', 'parseFormat', 'window', 'sliceBounds', 'createContext', 'destroyContext', 'cmap', 'cmapKeys', 'render', 'renderSync']) assert.strictEqual(typeof addon[k], 'function', k)
 assert.ok(addon.version >= 100)
 // format table, lib/samples.js:22-162
 for (const [name, sw] of [['cu8', 2], ['CFILE', 8], ['cs12', 3], ['nonsense', 2], ['CS64', 16], ['complex16s', 2]]) assert.strictEqual(addon.parseFormat(name).sampleWidth, sw, name)
@@ -20,6 +20,11 @@ for (const e of idx) {
     assert.ok(G.sameF64(w.weight, e.weight))
 }
 assert.throws(() => addon.window('kaiser', 8))
+// colour maps by name (sp_cmap): the reference's keys in its order, its lookup rules, its evaluated tables
+assert.strictEqual(addon.cmapKeys().length, 14)
+assert.strictEqual(addon.cmap('nosuch'), null)
+assert.strictEqual(addon.cmap('VIRIDIS').length, 3 * 256)
+assert.strictEqual(addon.cmap('para').length, 3 * 64)
 // slice bounds, lib/samples.js:253-258
 for (const c of G.spec.worker_cases) {
     const e = G.expected.find(x => x.name === c.name)

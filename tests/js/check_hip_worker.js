@@ -74,6 +74,30 @@ async function main() {
     assert.deepStrictEqual(order, [1, 2, 3, 4])
     assert.strictEqual(got, 0)
 
+    // terminate(): with a render in flight on a libuv thread and two more queued, nothing is reported any more, the queued
+    // requests never start, and the device context is released once the running render has returned (addon.destroyContext)
+    {
+        const addon = require('../../spectroplot-js_amd/lib/spectroplot_hip.node')
+        const w = new HipWorker()
+        let events = 0
+        w.onmessage = () => { events++ }
+        w.onerror = () => { events++ }
+        w.postMessage(mk(c1, 1)); w.postMessage(mk(c1, 2)); w.postMessage(mk(c1, 3))
+        await new Promise(r => setImmediate(r))                     // the first render is on its way
+        w.terminate()
+        w.terminate()                                               // idempotent
+        w.postMessage(mk(c2, 4))                                    // ignored
+        await new Promise(r => setTimeout(r, 300))
+        assert.strictEqual(events, 0, 'a terminated worker reported something')
+        assert.strictEqual(w._ctx, null)
+        // an idle context is released at once, and a released handle is refused
+        const h = addon.createContext(0)
+        assert.strictEqual(addon.destroyContext(h), true)
+        assert.throws(() => addon.renderSync(h, w._request(mk(c2, 5))), /destroyed/)
+        // many short-lived pools (renderSliced makes its own) must not pile up device contexts
+        for (let i = 0; i < 40; i++) { const t = new HipWorker(); t.terminate() }
+    }
+
     if (failures.length) { console.error(failures.slice(0, 30).join('\n')); console.error(`${failures.length} failures`); process.exit(1) }
     console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s)`)
 }

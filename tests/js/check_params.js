@@ -22,15 +22,19 @@ for (const e of K.clookups) assert.strictEqual(P.lookup(ckeys, e.key), e.hit, 'c
 assert.strictEqual(P.lookup(wkeys, null), null)
 assert.deepStrictEqual(P.lookup(wkeys, [1, 2]), [1, 2])
 
-// computed colour maps equal the reference's evaluated modules
+// every colour map of the reference, by key and through the reference's lookup rules, equals the reference's evaluated modules
 const idx = JSON.parse(fs.readFileSync(path.join(G.gdir, 'cmaps.json'), 'utf8'))
 const bin = fs.readFileSync(path.join(G.gdir, 'cmaps.bin'))
-for (const [name, lut] of Object.entries(P.computedCmaps)) {
-    const e = idx.find(x => x.name === name)
-    assert.strictEqual(lut.length, e.length, name)
+assert.deepStrictEqual(Object.keys(P.cmaps), K.cmap_key_order)
+for (const e of idx) {
+    const lut = P.cmaps[e.name]
+    assert.strictEqual(lut.length, e.length, e.name)
     const flat = Buffer.from(Uint8Array.from([].concat(...lut)))
-    assert.strictEqual(Buffer.compare(flat, bin.slice(e.offset, e.offset + 3 * e.length)), 0, name)
+    assert.strictEqual(Buffer.compare(flat, bin.slice(e.offset, e.offset + 3 * e.length)), 0, e.name)
 }
+for (const e of K.clookups) assert.strictEqual(P.lookup(P.cmaps, e.key), e.hit ? P.cmaps[e.hit] : null, 'cmap table lookup ' + e.key)
+assert.strictEqual(P.cmapByName('viridis'), P.cmaps.viridis_cmap)
+assert.strictEqual(P.cmapByName('nosuch'), P.cmaps.cube1_cmap)
 // named windows through the native library equal lib/windows.js
 const widx = JSON.parse(fs.readFileSync(path.join(G.gdir, 'windows.json'), 'utf8'))
 for (const e of widx.filter(x => x.n <= 1024)) {

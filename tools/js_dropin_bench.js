@@ -12,8 +12,13 @@ const siggen = require(path.join(root, 'oracle', 'js', 'siggen.js'))
 const { HipWorker } = require(path.join(root, 'spectroplot-js_amd', 'js'))
 
 const GEN = { kind: 'trinoise', seed: 0x5EED0001, step: 7321, gshift: 11, amp: 0.5, namp: 0.02 }
-function message(format, S, n, windowName) {
-    const bytes = siggen.generate(format, GEN, S, 0)
+function message(format, S, n, windowName, pinned) {
+    let bytes = siggen.generate(format, GEN, S, 0)
+    if (pinned) {   // the same samples in a page-locked ArrayBuffer (HipWorker.allocBuffer), as js/render_file.js cuts its slices
+        const p = new Uint8Array(HipWorker.allocBuffer(bytes.byteLength))
+        p.set(new Uint8Array(bytes.buffer, bytes.byteOffset, bytes.byteLength))
+        bytes = p
+    }
     const { window: windowc, weight } = O.makeWindow(windowName, n)
     const cmap = []
     for (let i = 0; i < 256; i++) cmap.push([i, 255 - i, (i * 3) & 255])
@@ -30,11 +35,14 @@ function ask(worker, m) {
 }
 async function main() {
     const worker = new HipWorker()
-    for (const [name, format, log2s, n, win] of [['config 1', 'CU8', 20, 512, 'hann'], ['config 2 / 4', 'CF32', 22, 1024, 'blackmanHarris'],
-        ['config 2', 'CF32', 24, 1024, 'blackmanHarris']]) {
-        const m = message(format, 2 ** log2s, n, win)
+    const json = process.argv.includes('--json')
+    const rows = []
+    for (const [name, format, log2s, n, win, pinned] of [['config 1', 'CU8', 20, 512, 'hann', false], ['config 2 / 4', 'CF32', 22, 1024, 'blackmanHarris', false],
+        ['config 2', 'CF32', 24, 1024, 'blackmanHarris', false], ['config 2, request buffer page-locked', 'CF32', 24, 1024, 'blackmanHarris', true]]) {
+        const m = message(format, 2 ** log2s, n, win, pinned)
         await ask(worker, m)                                   // warm-up: plan creation, first allocation
-        const reps = 5
+        await ask(worker, m)
+        const reps = 12
         let t0 = process.hrtime.bigint()
         let reply
         for (let i = 0; i < reps; i++) reply = await ask(worker, m)
@@ -47,8 +55,12 @@ async function main() {
             cpu_ms = Number(process.hrtime.bigint() - t0) / 1e6
             same = Buffer.compare(Buffer.from(ref.imageData.data.buffer), Buffer.from(reply.imageData.data.buffer)) === 0
         }
-        console.log(`${name}: ${format} 2^${log2s} samples, n=${n}: HipWorker ${gpu_ms.toFixed(2)} ms per message` +
+        rows.push({ name, format, samples: 2 ** log2s, n, request_buffer: pinned ? 'page-locked' : 'pageable', ms_per_message: gpu_ms,
+            msamples_per_s: 2 ** log2s / gpu_ms / 1e3, js_worker_ms: cpu_ms, images_identical: same })
+        if (!json) console.log(`${name}: ${format} 2^${log2s} samples, n=${n}: HipWorker ${gpu_ms.toFixed(2)} ms per message` +
             (cpu_ms ? `, JS worker ${cpu_ms.toFixed(0)} ms (x${(cpu_ms / gpu_ms).toFixed(0)}), images identical: ${same}` : ''))
     }
+    if (json) console.log(JSON.stringify(rows))
+    worker.terminate()
 }
 main().catch(e => { console.error(e); process.exit(1) })
