@@ -49,20 +49,64 @@ def load_cmap(name):
     return lut
 
 
-def cpu_baseline(fmt, n, window, seconds=12.0):
+def cpu_baseline(fmt, n, window, seconds=8.0):
     """Times the JavaScript oracle (bit-exact restatement of the reference worker, incl. its fft_nayuki radix-2 loop) under
-    Node on this host, single thread, on a bounded sample of the same workload."""
+    Node on this host on a bounded sample of the same workload, two legs: one thread, and one
+    worker_thread per host core as the reference starts one Web Worker per navigator.hardwareConcurrency
+    (lib/spectroplot.js:87).  `value` is the all-cores figure; the one-thread figure is reported beside it."""
     script = os.path.join(ROOT, "oracle", "js", "cpu_baseline.js")
-    log2_s = 22
+    cores = os.cpu_count() or 1
+
+    def leg(log2_s, threads):
+        out = subprocess.run(["node", script, fmt, str(log2_s), str(n), window, str(seconds), str(threads)], capture_output=True, text=True,
+                             timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
     try:
-        out = subprocess.run(["node", script, fmt, str(log2_s), str(n), window, str(seconds)], capture_output=True, text=True, timeout=300)
-        r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": r["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%s: 2^%d samples of the same synthetic %s signal, n=%d, %s, %d renders in %.1f s, node %s, 1 thread of %d host cores"
-                          % ("oracle/js/worker_oracle.js", log2_s, fmt, n, window, r["reps"], r["seconds"], r["node"], os.cpu_count()),
-                "msamples_per_s": r["msamples_per_s"]}
+        one = leg(22, 1)
+        res = {"value": one["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "oracle/js/worker_oracle.js under node %s: 2^22 samples of the same synthetic %s signal, n=%d, %s, %d renders in %.1f s "
+                         "on 1 thread of %d host cores" % (one["node"], fmt, n, window, one["reps"], one["seconds"], cores),
+               "msamples_per_s": one["msamples_per_s"], "one_thread": {"frames_per_s": one["frames_per_s"], "msamples_per_s": one["msamples_per_s"]}}
     except Exception as e:  # the baseline is reported, never required
         return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    try:
+        if cores > 1:
+            allc = leg(20, cores)
+            res.update({"value": allc["frames_per_s"], "cores": cores, "msamples_per_s": allc["msamples_per_s"],
+                        "sample": res["sample"] + "; all-cores leg: %d worker_threads, each rendering 2^20 samples of the signal for %.1f s"
+                                  % (cores, allc["seconds"])})
+    except Exception as e:
+        res["all_cores_failed"] = repr(e)
+    return res
+
+
+def e2e_dropin():
+    """The message path a caller of the reference sees: postMessage -> onmessage through HipWorker (N-API, host buffers, PCIe both
+    ways), tools/js_dropin_bench.js under Node.  Reported beside the HBM-resident figure, never as `value`."""
+    try:
+        out = subprocess.run(["node", os.path.join(ROOT, "tools", "js_dropin_bench.js"), "--json"], capture_output=True, text=True, timeout=600)
+        rows = json.loads(out.stdout.strip().splitlines()[-1])
+        pick = {r["name"]: r for r in rows}
+        a, b = pick["config 2"], pick["config 2, request buffer page-locked"]
+        return {"workload": "one config-2 worker message (16 MSample cf32 in, 64 MiB RGBA out) through HipWorker under Node",
+                "ms_per_message": a["ms_per_message"], "msamples_per_s": a["msamples_per_s"],
+                "ms_per_message_pinned_request": b["ms_per_message"], "msamples_per_s_pinned_request": b["msamples_per_s"],
+                "config1_ms_per_message": pick["config 1"]["ms_per_message"], "config1_js_worker_ms": pick["config 1"]["js_worker_ms"]}
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
+def launch_ranks(argv, gpus):
+    """`python bench.py --gpus N` started plainly: one child rank per GPU through torch.distributed.run, before this process has
+    touched the GPU; the children's output (rank 0 prints the JSON line) passes through."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
@@ -72,13 +116,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the RGBA strips to rank 0")
+    ap.add_argument("--gather", action="store_true", help="(default when N > 1) also time the RCCL gather of the RGBA strips to rank 0")
+    ap.add_argument("--no-gather", action="store_true", help="skip the strip gather")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the Node drop-in leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "lds", "frames"], help="A/B runs: force a device kernel")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
 
     import numpy as np
     import torch
@@ -89,8 +138,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     if args.oversubscribe:
@@ -215,7 +263,7 @@ def main():
     kernel_ms = max(kernel_ms_events - event_overhead_ms, 0.5 * kernel_ms_events)
 
     gather_ms = None
-    if dist is not None and args.gather:
+    if dist is not None and not args.no_gather:
         strips = [torch.empty_like(rgba) for _ in range(world)] if rank == 0 else None
         sync()
         g0 = time.perf_counter()
@@ -230,7 +278,7 @@ def main():
     frames_per_s = world * W * args.steps / dt
 
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.config)
+    tfile = os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % args.config)
     if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
 
@@ -244,6 +292,9 @@ def main():
             "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W, "format": fmt, "n": n,
                        "samples_per_gpu": S, "frames_per_gpu": W, "window": window, "cmap": cmap,
                        "sharding": "contiguous time slice per GPU" if world > 1 else "single GPU",
+                       "butterfly_graph": "the reference's radix-2 DIT graph (lib/fft_nayuki.js:54-96) in f64 without fused multiply-adds, executed "
+                                          "as 16-point register passes with LDS / register re-distribution between them (not a Stockham "
+                                          "re-factorisation: any other factorisation changes the rounding and with it RGBA bytes)",
                        "generator": "trinoise seed=0x%08X step=%d gshift=%d amp=%g namp=%g" % (GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])},
             "msamples_per_s": frames_per_s * stride_eff / 1e6,
             "kernel": plan.kernel_name(),
@@ -258,7 +309,13 @@ def main():
             out["rgba_gather_GBps"] = (world - 1) * rgba.numel() / (gather_ms * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fmt, n, window)
+        if world == 1 and not args.no_e2e and args.config == "cfg2":
+            out["e2e"] = e2e_dropin()
         print(json.dumps(out))
+        if hsum != world * W * n:
+            print("bench.py: colour histogram total %d != %d pixels" % (hsum, world * W * n), file=sys.stderr)
+            plan.close()
+            sys.exit(1)
     plan.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -20,7 +20,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/pass$i.log 2>&1
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $ROOT/gpurun_out/pmc_${TAG}_summary.txt 2>&1
 cat $ROOT/gpurun_out/pmc_${TAG}_summary.txt
