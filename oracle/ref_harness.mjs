@@ -347,6 +347,92 @@ const run = async () => {
         fs.writeFileSync(path.join(outdir, 'consumers.json'), JSON.stringify(out, null, 0))
     }
 
+    // ---- the reference's own caller: startWorkers + processData, unmodified, against a Worker-shaped class ------------------------
+    // (lib/spectroplot.js:100-130, :1096-1285).  The module reads navigator.hardwareConcurrency once when it is loaded, so it is
+    // imported once per worker count (a query string makes each import a module instance of its own).  The class handed to
+    // startWorkers forwards every message to the REAL lib/worker.js loaded above and answers asynchronously, like a worker thread;
+    // its instances are Proxies that note which members the reference touches.  processData runs on a stand-in `this` whose
+    // canvases record what they are asked to draw.
+    {
+        const savedLog = console.log, savedTime = console.time, savedTimeEnd = console.timeEnd, savedErr = console.error
+        const quiet = () => { console.log = () => {}; console.time = () => {}; console.timeEnd = () => {}; console.error = () => {} }
+        const loud = () => { console.log = savedLog; console.time = savedTime; console.timeEnd = savedTimeEnd; console.error = savedErr }
+        const out = { runs: [] }
+        for (const W of spec.caller_kat.workers) {
+            quiet()
+            globalThis.navigator = { hardwareConcurrency: W }
+            globalThis.window = { File: 1, FileReader: 1, FileList: 1, Blob: 1, Worker: function Worker() {}, innerHeight: 0, addEventListener() {},
+                dispatchEvent() {} }
+            globalThis.createImageBitmap = () => new Promise(() => {})        // "mostly unsupported": never resolves, nothing is restored
+            globalThis.ImageData = class ImageData { constructor(data, width, height) { this.data = data; this.width = width; this.height = height || data.length / 4 / width } }
+            const SPW = await import('./lib/spectroplot.js?workers=' + W)
+            const touched = { get: new Set(), set: new Set() }
+            const messages = []
+            class RefWorker {
+                constructor() {
+                    this.onmessage = null
+                    return new Proxy(this, {
+                        get(t, k) { if (typeof k === 'string') touched.get.add(k); return t[k] },
+                        set(t, k, v) { if (typeof k === 'string') touched.set.add(k); t[k] = v; return true },
+                    })
+                }
+                postMessage(message, transfer) {
+                    messages.push({ message, transfer })
+                    captured = null
+                    globalThis.onmessage({ data: message })                   // the real worker: ignores messages without a buffer
+                    const reply = captured
+                    if (reply) Promise.resolve().then(() => this.onmessage({ data: reply }))
+                }
+            }
+            SPW.startWorkers(RefWorker)
+            const probe = messages.splice(0, messages.length)
+            const run = { workers: W, members_read: Array.from(touched.get).sort(), members_written: Array.from(touched.set).sort(),
+                probe: probe.map(p => ({ keys: Object.keys(p.message), transfer: p.transfer.length })), cases: [] }
+            for (const c of spec.caller_kat.cases) {
+                const input = makeInput(c)
+                const mkcanvas = (name) => {
+                    const calls = []
+                    const ctx = { calls, fillStyle: '',
+                        getImageData: (x, y, w, h) => ({ data: new Uint8ClampedArray(4 * Math.max(w, 1) * Math.max(h, 1)), width: w, height: h }),
+                        drawImage() { calls.push(['drawImage']) },
+                        putImageData(d, x, y) { calls.push(['putImageData', x, y, d.width, d.height, sha256(d.data)]) },
+                        fillRect(x, y, w, h) { calls.push(['fillRect', x, y, w, h, this.fillStyle]) } }
+                    return { name, width: 0, height: 0, style: {}, ctx, getContext: () => ctx }
+                }
+                const canvases = { fft: mkcanvas('fft'), minmax: mkcanvas('minmax'), amp: mkcanvas('amp') }
+                const scroll = { scrollLeft: 0, scrollLeftMax: 0 }
+                const hist = {}
+                const cmap = cmaps[c.cmap + '_cmap'].map(e => e.slice())
+                const self = {
+                    buffer: input.buffer.slice(input.byteOffset, input.byteOffset + input.byteLength), inProcess: false, tag: 'kat', turnFlip: !!c.waterfall,
+                    opts: { freqWidth: 0, dbfsWidth: 0 }, histWidth: 0, zoom: 1, fftN: c.n, windowF: windows[c.window + 'Window'], gain: c.gain, range: c.range,
+                    cmap, channelMode: !!c.channelMode, height: 0, minmaxHeight: c.minmaxHeight, ampHeight: c.ampHeight, scrollElY: { scrollTop: 0 }, zoomPoint: null,
+                    parent: { clientWidth: c.width, getElementsByClassName: (cls) => cls === 'scroll' ? [scroll] : [canvases[cls]] },
+                    drawColorRamp() {}, drawAxes() {}, buildInfo() {},
+                    drawHistograms(c_hist, cB_hist) { hist.c_hist = Array.from(c_hist); hist.cB_hist = {}; cB_hist.forEach((v, i) => { if (v) hist.cB_hist[i] = v }) },
+                }
+                self.sampleView = new SampleView(c.format, self.buffer)
+                globalThis.window.innerHeight = c.width
+                await SPW.Spectroplot.prototype.processData.call(self)
+                const sent = messages.splice(0, messages.length)
+                run.cases.push({ name: c.name, width: self.width,
+                    canvas: { fft: [canvases.fft.width, canvases.fft.height], minmax: [canvases.minmax.width, canvases.minmax.height],
+                        amp: [canvases.amp.width, canvases.amp.height] },
+                    messages: sent.map(p => ({ block_norm: f64hex(p.message.block_norm), gain: p.message.gain, range: p.message.range, n: p.message.n,
+                        width: p.message.width, offset: p.message.offset, format: p.message.format, channelMode: p.message.channelMode,
+                        waterfall: p.message.waterfall, buffer_bytes: p.message.buffer.byteLength, transfer_is_buffer: p.transfer.length === 1 && p.transfer[0] === p.message.buffer,
+                        cmap_len: p.message.cmap.length, cmap_first: p.message.cmap[0], cmap_last: p.message.cmap[p.message.cmap.length - 1],
+                        windowc_sha256: crypto.createHash('sha256').update(f64bytes(p.message.windowc)).digest('hex') })),
+                    fft_calls: canvases.fft.ctx.calls.filter(k => k[0] === 'putImageData'),
+                    minmax_calls: canvases.minmax.ctx.calls, amp_calls: canvases.amp.ctx.calls,
+                    c_hist: hist.c_hist, cB_hist: hist.cB_hist, dBfs_min: f64hex(self.dBfs_min), dBfs_max: f64hex(self.dBfs_max), inProcess_after: self.inProcess })
+            }
+            loud()
+            out.runs.push(run)
+        }
+        fs.writeFileSync(path.join(outdir, 'caller.json'), JSON.stringify(out, null, 0))
+    }
+
     fs.writeFileSync(path.join(outdir, 'provenance.json'), JSON.stringify({
         generated_by: 'oracle/gen_golden.js + oracle/ref_harness.mjs',
         reference: 'triq-org/spectroplot-js lib/worker.js (v1.2.1, /root/reference)',

@@ -11,8 +11,8 @@
  *   gaugeColumns               lib/spectroplot.js:1246-1268 (per-reply gauge strips inside processData)
  *
  * colorRamp, rampMarkers and histogramOutlines are pinned call-for-call against the reference's own methods run on a
- * recording context (tests/golden/consumers.json, oracle/ref_harness.mjs).  gaugeColumns restates an inline block of
- * processData that cannot be called on its own; it has no reference vector (see its docstring).
+ * recording context (tests/golden/consumers.json, oracle/ref_harness.mjs); gaugeColumns against the fillRect calls the reference's
+ * processData itself makes on recording canvases when run with 1, 2 and 8 workers (tests/golden/caller.json).
  */
 
 const DEFAULT_THEME = { rampFill: '#666', histoLine: 2, histoStroke: '#b0b', histoFill: 'rgba(187,0,187,0.2)', dbfsLine: 2,
@@ -84,8 +84,8 @@ function histogramOutlines(o) {
 /**
  * The gauge strips of one reply: per column a grey level `255 - gauge_max` and the two bars the reference fills
  * (lib/spectroplot.js:1246-1268): min/max bar from `~~(g_min*scale)` of height `~~((g_max-g_min)*scale)`, amplitude bar of
- * height `~~(g_amp*ampScale)`, at x = column + reply.offset.  NOT pinned by a reference vector: the block is inline in
- * processData's promise handler and cannot be run apart from the DOM-bound render; it is restated from its arithmetic.
+ * height `~~(g_amp*ampScale)`, at x = column + reply.offset.  Pinned by the fillRect calls of the reference's own processData
+ * run on recording canvases (tests/golden/caller.json, tests/js/check_caller.js).
  */
 function gaugeColumns(reply, sliceWidth, minmaxHeight, ampHeight) {
     const out = { minmax: [], amp: [] }

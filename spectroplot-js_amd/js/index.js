@@ -1,7 +1,7 @@
 'use strict'
 /** Node entry point: `const { HipWorker } = require('spectroplot-js_amd/js')` then `new Spectroplot({workerOrUrl: HipWorker, ...})`. */
 const { HipWorker, packLut } = require('./hip_worker.js')
-const { renderSliced } = require('./render_file.js')
+const { renderSliced, stripPlacement } = require('./render_file.js')
 const params = require('./params.js')
 const consumers = require('./consumers.js')
-module.exports = Object.assign({ HipWorker, packLut, renderSliced }, params, consumers)
+module.exports = Object.assign({ HipWorker, packLut, renderSliced, stripPlacement }, params, consumers)

@@ -43,7 +43,8 @@ function renderSliced(o, pool) {
         const [b0, b1] = a.sliceBounds(o.buffer.byteLength, fmt.sampleWidth, i, workers)
         // the slice is a copy, as in the reference (SampleView.slice -> ArrayBuffer.slice); here it lands in page-locked memory,
         // from where the GPU fetches it at the full rate of the host link
-        const slice = a.allocBuffer(b1 - b0)
+        // (without a device there is nothing to lock pages for: a caller-supplied pool of other workers gets a plain copy)
+        const slice = a.deviceCount() > 0 ? a.allocBuffer(b1 - b0) : new ArrayBuffer(b1 - b0)
         new Uint8Array(slice).set(new Uint8Array(o.buffer, b0, b1 - b0))
         const message = { block_norm, gain, range, cmap, n, windowc: w.window, width: sliceWidth, offset: i * sliceWidth,
             buffer: slice, format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
@@ -60,11 +61,9 @@ function renderSliced(o, pool) {
             for (let k = 0; k < 1000; k++) cB_hist[k] += r.cB_hist[k]
             for (let k = 0; k < cmap.length; k++) c_hist[k] += r.c_hist[k]
             const img = r.imageData.data
-            if (!o.waterfall) {                                          // putImageData(strip, offset, 0)
-                for (let y = 0; y < n; y++) merged.set(img.subarray(4 * y * sliceWidth, 4 * (y + 1) * sliceWidth), 4 * (y * width + r.offset))
-            } else {                                                     // putImageData(strip, 0, width - sliceWidth - offset)
-                merged.set(img, 4 * n * (width - sliceWidth - r.offset))
-            }
+            const [px, py, pw, ph] = stripPlacement(r, { width, sliceWidth, n, waterfall: !!o.waterfall })
+            const canvasWidth = o.waterfall ? n : width
+            for (let y = 0; y < ph; y++) merged.set(img.subarray(4 * y * pw, 4 * (y + 1) * pw), 4 * ((py + y) * canvasWidth + px))
         }
         pool.forEach((wk, k) => { wk.onmessage = saved[k][0]; wk.onerror = saved[k][1] })
         if (own) pool.forEach(wk => wk.terminate())
@@ -73,4 +72,15 @@ function renderSliced(o, pool) {
     })
 }
 
-module.exports = { renderSliced }
+/**
+ * Where the caller puts a reply's strip: putImageData(newImageData(data, waterfall ? n : sliceWidth), x, y) with
+ * (x, y) = (offset, 0), or (0, width - sliceWidth - offset) for the waterfall layout (lib/spectroplot.js:1241-1244).
+ * @returns {[number, number, number, number]} x, y, strip width, strip height
+ */
+function stripPlacement(reply, o) {
+    const w = o.waterfall ? o.n : o.sliceWidth
+    const h = reply.imageData.data.length / 4 / w
+    return o.waterfall ? [0, o.width - o.sliceWidth - reply.offset, w, h] : [reply.offset, 0, w, h]
+}
+
+module.exports = { renderSliced, stripPlacement }

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node not i
 ADDON = os.path.join(ROOT, "spectroplot-js_amd", "lib", "spectroplot_hip.node")
 
 
-def _node(script, timeout=600):
+def _node(script, *args, timeout=600):
     if not os.path.exists(ADDON):
         build()
-    return subprocess.run(["node", os.path.join(ROOT, "tests", "js", script)], capture_output=True, text=True, timeout=timeout)
+    return subprocess.run(["node", os.path.join(ROOT, "tests", "js", script)] + list(args), capture_output=True, text=True, timeout=timeout)
 
 
 def test_addon_loads_and_host_helpers_match_reference_kats():
@@ -35,6 +35,22 @@ def test_side_output_consumers_match_reference_draw_calls():
     out = _node("check_consumers.js")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "consumers checks ok" in out.stdout
+
+
+def test_slice_merge_and_gauges_reproduce_the_references_own_caller():
+    """renderSliced / stripPlacement / gaugeColumns against what the reference's startWorkers + processData did with 1, 2 and 8
+    workers (tests/golden/caller.json), the workers being the JavaScript oracle here."""
+    out = _node("check_caller.js", "oracle")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "caller checks ok (oracle): 9" in out.stdout
+
+
+@pytest.mark.gpu
+def test_hip_worker_pool_reproduces_the_references_own_caller():
+    """The same with a pool of HipWorker instances, the product's workers."""
+    out = _node("check_caller.js", "hip")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "caller checks ok (hip): 9" in out.stdout
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, case_names, out_dir):
+def _rank_main(rank, world, port, case_names, out_dir, renderer="oracle"):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,13 +39,20 @@ def _rank_main(rank, world, port, case_names, out_dir):
         return {"cB_hist": r["cB_hist"], "c_hist": r["c_hist"], "dBfs_min": r["dBfs_min"], "dBfs_max": r["dBfs_max"],
                 "offset": m["offset"], "imageData": {"data": r["rgba"]}}
 
+    worker = oracle_worker
+    hip = None
+    if renderer == "hip":   # the product's renderer: every rank drives its own HipWorker (ranks share GPU 0 on a one-GPU box)
+        import torch
+        hip = pkg.HipWorker(rank % max(1, torch.cuda.device_count()))
+        worker = hip.render
+
     ok = True
     for name in case_names:
         c, e = g.cases[name], g.expected[name]
         data = g.input(c)
         win, weight = pyoracle.window(c["window"], c["n"])
         cmap = g.lut(c, force_ends=False).tolist()
-        m = sharding.render_sharded(oracle_worker, data, c["format"], c["n"], c["width"], win, weight, cmap, c["gain"], c["range"],
+        m = sharding.render_sharded(worker, data, c["format"], c["n"], c["width"], win, weight, cmap, c["gain"], c["range"],
                                     c["channelMode"], c["waterfall"], force_ends=c["force_ends"])
         ok &= [int(v) for v in m["c_hist"]] == e["merged"]["c_hist"]
         ok &= goldenlib.same_f64(m["dBfs_min"], e["merged"]["dBfs_min"]) and goldenlib.same_f64(m["dBfs_max"], e["merged"]["dBfs_max"])
@@ -58,6 +65,8 @@ def _rank_main(rank, world, port, case_names, out_dir):
             ok &= goldenlib.sha256(m["data"]) == e["merged"]["rgba_sha256"]
         else:
             ok &= m["data"] is None
+    if hip is not None:
+        hip.terminate()
     with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
         f.write("ok" if ok else "FAIL")
     dist.destroy_process_group()
@@ -69,3 +78,16 @@ def test_two_ranks_reproduce_reference_two_worker_merge(tmp_path, golden):
     mp.spawn(_rank_main, args=(2, _free_port(), names, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "rank0").read() == "ok"
     assert open(tmp_path / "rank1").read() == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_with_the_product_renderer_reproduce_reference_merge(tmp_path, golden, world):
+    """sharding.render_sharded with HipWorker.render as every rank's worker (the 8-GPU path of BASELINE config 4, with the ranks
+    sharing the one GPU of this box; gloo carries the merge collectives): slices, side outputs and the merged image against the
+    reference run with `world` workers."""
+    names = [n for n, c in golden.cases.items() if c.get("slices") == world]
+    assert names
+    mp.spawn(_rank_main, args=(world, _free_port(), names, str(tmp_path), "hip"), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("rank%d" % r)).read() == "ok", r
