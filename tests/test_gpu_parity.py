@@ -271,6 +271,9 @@ def test_random_requests_against_oracle(pkg, ctx, case):
     ("config3_cs16_n2048", "CS16", 25, 2048, None, "hann"),
     ("config4_slice_cu8_n1024", "CU8", 26, 1024, None, "blackmanHarris"),
     ("config5_cs12_n8192_zoom8", "CS12", 23, 8192, (1 << 23) // 8192 * 8, "blackmanHarris"),
+    # BASELINE configs 3 and 5 at full size (1 GiB in / 1 GiB out; 192 MiB in / 2 GiB out)
+    ("config3_full_cs16_n2048", "CS16", 28, 2048, None, "hann"),
+    ("config5_full_cs12_n8192_zoom8", "CS12", 26, 8192, (1 << 26) // 8192 * 8, "blackmanHarris"),
 ], ids=lambda c: c[0])
 def test_baseline_config_shapes_sampled_frames(pkg, ctx, golden, cfg):
     """The other BASELINE.json configurations (length scaled down, shape kept: format, n, hop / 8x overlap, window) on
@@ -308,6 +311,92 @@ def test_baseline_config_shapes_sampled_frames(pkg, ctx, golden, cfg):
     for p in ptrs + [d_in]:
         ctx.free(p)
     plan.close()
+
+
+def test_pixels_straddling_every_index_edge(pkg, ctx):
+    """k_frames decides colour index and centi-bel bin from an f32 value and sends only the lanes within a proven error margin of
+    a step to the exact edge tables (sp_host.cpp).  This test puts |X|^2 onto both sides of EVERY step of both scales, a few ulps
+    apart: a frame whose only non-zero sample is (x, 0) under a rectangular taper has |X|^2 = x*x in all its bins, exactly, and
+    x runs over the doubles around the square root of every edge.  The edges are located with the oracle's own log10."""
+    import ctypes
+    n, fmt = 64, "CF64"
+    gain, rng, L = 6.0, 30.0, 256
+    block_norm = 1.0 / n
+    log10 = pyoracle.lib().spo_log10
+    bndb = 10 * log10(block_norm)
+    cmax, color_norm = L - 1, L / -rng
+
+    def gray(a2):
+        u = cmax - (5 * log10(a2) + bndb + gain) * color_norm
+        return int(0.5 + (0 if u < 0 else cmax if u > cmax else u))
+
+    def cbin(a2):
+        v = 0.5 + ((5 * log10(a2) + bndb + gain) - gain) * -10
+        return min(int(v), 999) if v > -1 else -1 if int(v) < 0 else 0
+
+    def edges(f, lo, hi):
+        """smallest doubles in [lo, hi] at which f changes, by bisection over bit patterns (f is monotone there)"""
+        out = []
+        a, b = np.float64(lo).view(np.uint64), np.float64(hi).view(np.uint64)
+
+        def rec(a, fa, b, fb):
+            if fa == fb:
+                return
+            if b - a == 1:
+                out.append(np.uint64(b).view(np.float64))
+                return
+            m = a + (b - a) // 2
+            fm = f(float(np.uint64(m).view(np.float64)))
+            rec(a, fa, m, fm)
+            rec(m, fm, b, fb)
+        rec(int(a), f(float(lo)), int(b), f(float(hi)))
+        return out
+
+    es = edges(gray, 1e-18, 1e5) + edges(cbin, 1e-18, 1e5)
+    assert len(es) > 1200
+    xs = []
+    for e in es:
+        r = np.sqrt(np.float64(e))
+        for k in range(-2, 3):
+            xs.append(np.uint64(int(r.view(np.uint64)) + k).view(np.float64))
+    xs = np.array(xs, dtype=np.float64)
+    W = len(xs)
+    cap = np.zeros((W, n, 2), dtype=np.float64)
+    cap[:, 0, 0] = xs
+    data = cap.reshape(-1).view(np.uint8)
+    win = np.ones(n, dtype=np.float64)
+    i = np.arange(L)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(fmt, data, n, win, block_norm, gain, rng, lut, W)
+    for kernel in ("frames", "lds", "scratch"):
+        got = _plan_render(pkg, ctx, kernel, fmt, data, n, win, block_norm, gain, rng, lut, W, False, False)
+        assert got is not None and got["kernel"] == {"frames": "frames", "lds": "lds_r16", "scratch": "scratch_radix2"}[kernel]
+        assert np.array_equal(got["rgba"], want["rgba"]), kernel
+        assert np.array_equal(got["c_hist"].astype(np.int64), want["c_hist"]), kernel
+        assert np.array_equal(got["cB_hist"].astype(np.int64), want["cB_hist"]), kernel
+        assert np.float64(got["dBfs_min"]).view(np.uint64) == np.float64(want["dBfs_min"]).view(np.uint64), kernel
+    # the squares really fall on both sides of the steps: both colours of most edges occur
+    assert len(np.unique(want["rgba"].reshape(-1, 4)[:, 0])) > 250
+
+
+def test_nonfinite_taper_is_exact(pkg, ctx):
+    """A caller-supplied taper may hold infinities or NaN (options.windowF is any function).  Inf * 1 + Inf * 0 is NaN in the
+    reference's first butterfly, so the kernels that skip the products of (1, 0) butterflies must not serve such a plan."""
+    n, W, fmt = 1024, 40, "CS16"
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 5, "step": 4099, "gshift": 9, "amp": 0.5, "namp": 0.02}, n * W)
+    win, weight = pyoracle.window("hann", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    for bad in ([(n // 2, np.inf)], [(3, np.nan)], [(0, -np.inf), (n - 1, np.inf)]):
+        w = win.copy()
+        for pos, v in bad:
+            w[pos] = v
+        plan = ctx.plan(fmt, n, w, 1.0 / weight, 6.0, 30.0, lut)
+        assert plan.kernel_name() == "scratch_radix2"
+        plan.close()
+        want = pyoracle.render(fmt, data, n, w, 1.0 / weight, 6.0, 30.0, lut, W)
+        got = ctx.render(fmt, data, n, w, 1.0 / weight, 6.0, 30.0, lut, W)
+        _assert_same(got, want)
 
 
 def _assert_same(got, want):
