@@ -10,6 +10,17 @@
  * values produced by that engine), the twiddle tables and the window tables of the reference run.
  *
  * Compile with -ffp-contract=off: every operation must round separately, as it does in the engine.
+ *
+ * The routines below follow Sun Microsystems' fdlibm 5.3, whose files carry this notice, which is kept here as required:
+ *
+ *   ====================================================
+ *   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ *   Developed at SunSoft, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this
+ *   software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
  */
 #ifndef SP_ORACLE_V8MATH_H
 #define SP_ORACLE_V8MATH_H

@@ -1,6 +1,7 @@
 """ctypes binding of include/spectroplot_hip.h.  No compute happens in Python."""
 import ctypes as C
 import os
+import weakref
 import subprocess
 
 import numpy as np
@@ -34,8 +35,9 @@ class _Reply(C.Structure):
 
 
 def lib_path():
-    # SP_LIB_VARIANT=<name> loads lib/variants/<name>.so instead (kernel experiments built with other compile-time options)
-    v = os.environ.get("SP_LIB_VARIANT")
+    # Kernel experiments only (tools/build_variant.sh, tools/ab_variants.sh): with SP_EXPERIMENT_KNOBS=1 in the environment,
+    # SP_LIB_VARIANT=<name> loads lib/variants/<name>.so, a copy of the library built with other compile-time options.
+    v = os.environ.get("SP_LIB_VARIANT") if os.environ.get("SP_EXPERIMENT_KNOBS") == "1" else None
     if v:
         return os.path.join(_HERE, "lib", "variants", v + ".so")
     return os.path.join(_HERE, "lib", "libspectroplot_hip.so")
@@ -163,9 +165,13 @@ class Context:
         self.lib.check(self.lib.L.sp_context_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._plans = weakref.WeakSet()   # live Plan objects of this context
 
     def close(self):
         if self.h:
+            # plans hold a pointer to their context: they go first (a Plan object that outlives this call is inert)
+            for p in list(self._plans):
+                p.close()
             self.lib.L.sp_context_destroy(self.h)
             self.h = None
 
@@ -262,6 +268,7 @@ class Plan:
         h = C.c_void_p()
         ctx._chk(ctx.lib.L.sp_plan_create(ctx.h, C.byref(req), C.byref(h)))
         self.h = h
+        ctx._plans.add(self)
 
     def close(self):
         if self.h:

@@ -5,6 +5,18 @@
 // (e_log.c, e_log10.c, k_cos.c, k_sin.c, e_rem_pio2.c); they are restated here so that tables and thresholds built
 // by this library are bit-identical to what the reference computes under Node.  Everything must be compiled with
 // -ffp-contract=off: each operation rounds on its own.
+//
+// The routines follow Sun Microsystems' fdlibm 5.3 (constants and evaluation order are the algorithm); its notice is kept here
+// as it requires:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 
 #include <cstdint>

@@ -25,6 +25,15 @@ function addon() {
 
 let nextDevice = 0
 
+// Renders run on libuv's thread pool (4 threads unless UV_THREADPOOL_SIZE says otherwise, shared with fs / dns work), one thread
+// per render in flight: a pool of N HipWorkers on N GPUs needs N of them.  The size is read when the pool first starts, so it is
+// raised here, at load time, if nothing has been set; applications that have already used the pool must set it themselves.
+function reserveThreads(devices) {
+    const want = devices + 4
+    const have = parseInt(process.env.UV_THREADPOOL_SIZE || '0', 10)
+    if (!(have >= want)) process.env.UV_THREADPOOL_SIZE = String(Math.min(want, 1024))
+}
+
 /** cmap entries -> packed Uint8Array with the store semantics of the reference's Uint8ClampedArray image (worker.js:118-121). */
 function packLut(cmap) {
     const lut = new Uint8ClampedArray(cmap.length * 3)
@@ -43,6 +52,7 @@ class HipWorker {
         this._queue = Promise.resolve()
         this._closed = false
         const n = addon().deviceCount()
+        if (nextDevice === 0) reserveThreads(n)
         if (n < 1) throw Object.assign(new Error('no HIP device: spectroplot-hip has no CPU fallback'), { status: -5 })
         this.device = options && options.device !== undefined ? options.device : (nextDevice++ % n)
         this._ctx = addon().createContext(this.device)

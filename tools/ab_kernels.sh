@@ -3,7 +3,7 @@
 #   tools/ab_kernels.sh "<kernel> ..." [config] [extra bench args]      kernels: lds frames auto; SP_LIB_VARIANT honoured
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${2:-cfg2}
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp SP_EXPERIMENT_KNOBS=1
 for rep in 1 2; do
 for k in $1; do
   rm -rf /tmp/ab_$k

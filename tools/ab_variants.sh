@@ -3,7 +3,7 @@
 #   tools/ab_variants.sh "<variant> ..." [config] [kernel] [extra bench args]     ("-" = the library in lib/)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${2:-cfg2}; K=${3:-frames}
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp SP_EXPERIMENT_KNOBS=1
 for rep in 1 2; do
 for v in $1; do
   if [ "$v" = "-" ]; then unset SP_LIB_VARIANT; else export SP_LIB_VARIANT=$v; fi

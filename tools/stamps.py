@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave phase clocks of k_frames from a library built with -DSP_STAMPS (tools/build_variant.sh stamps -DSP_STAMPS).
-   SP_LIB_VARIANT=stamps python3 tools/stamps.py [cfg]"""
+   SP_EXPERIMENT_KNOBS=1 SP_LIB_VARIANT=stamps python3 tools/stamps.py [cfg]"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
