@@ -46,6 +46,9 @@
 #ifndef SP_HIST_COPIES
 #define SP_HIST_COPIES 1   // LDS histogram copies dealt over lanes (1, 2)
 #endif
+#ifndef SP_ASM_READS
+#define SP_ASM_READS 1     // exchange reads as single ds_read_b64 (the compiler pairs them into half-rate ds_read2_b64)
+#endif
 
 namespace spk {
 
@@ -228,8 +231,28 @@ __device__ inline void exchange(double (&v)[16], double *from, const double *to)
 #pragma unroll
     for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
     frame_sync<BLOCK_SYNC>();
+#if SP_ASM_READS
+    // one ds_read_b64 per value: the compiler pairs them into ds_read2_b64, which the LDS serves at half the rate per byte
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)to;
+#pragma unroll
+    for (int e = 0; e < 16; e++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[e]) : "v"(addr), "n"(win_off(e, WS_TO) * 8));
+    // the caller waits for them with exchange_wait() once both components are on their way
+#else
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = to[win_off(e, WS_TO)];
+#endif
+}
+
+// The compiler does not see the reads of exchange() when they are written as asm (SP_X_ASM_READS): every value passes through
+// this wait before it is used.
+__device__ inline void exchange_wait(double (&re)[16], double (&im)[16])
+{
+#if SP_ASM_READS
+#define SP_W8(v, o) "+v"(v[o]), "+v"(v[o + 1]), "+v"(v[o + 2]), "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), "+v"(v[o + 7])
+    asm volatile("s_waitcnt lgkmcnt(0)" : SP_W8(re, 0), SP_W8(re, 8)::"memory");
+    asm volatile("" : SP_W8(im, 0), SP_W8(im, 8)::"memory");
+#undef SP_W8
+#endif
 }
 
 // ---- second re-distribution without LDS (n = 512, 1024; one frame per wave or half-wave) ----------------------------
@@ -332,7 +355,11 @@ __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start
             lo[e] = *(const uint32_t *)p;
         } else {
             // keep the two words of a sample in one 64-bit load result (an even-aligned register pair)
+#ifdef SP_X_NT_LOAD
+            const unsigned long long w = __builtin_nontemporal_load((const unsigned long long *)p);
+#else
             const unsigned long long w = *(const unsigned long long *)p;
+#endif
             lo[e] = (uint32_t)w;
             hi[e] = (uint32_t)(w >> 32);
         }
@@ -672,6 +699,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                exchange_wait(re, im);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
                 if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
@@ -687,6 +715,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                     } else {
                         exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
                         exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                exchange_wait(re, im);
                     }
                     if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
                     else fft_pass<WS2, 9, E2>(re, im, tw2);
@@ -697,6 +726,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         load_pass_tw(tw3, tl, s_tw, tw);
                         exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
                         exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
+                exchange_wait(re, im);
                         fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
                 }
