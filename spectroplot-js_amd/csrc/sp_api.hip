@@ -541,7 +541,7 @@ static bool plan_lds_capable(const sp_plan *plan)
 
 static bool plan_frames_capable(const sp_plan *plan)
 {
-    return plan_lds_capable(plan) && spk2::frames_kernel_supports(plan->req.n, spk2::frames_waves(plan->levels)) && plan->th.frames_ok && plan->tw16_ok;
+    return plan_lds_capable(plan) && spk2::frames_kernel_supports(plan->req.n, 8) && plan->th.frames_ok && plan->tw16_ok;
 }
 
 // 1 = scratch_radix2, 2 = lds_r16, 3 = frames

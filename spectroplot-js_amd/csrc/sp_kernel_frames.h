@@ -82,7 +82,7 @@ struct Layout {
     int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_win, total;
 };
 
-__host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds)
+__host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds, bool win_lds = true)
 {
     Layout l;
     const int fpb = threads * 16 / n;
@@ -96,7 +96,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     l.off_lut = o;    o += lut_len * 4;
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
     o = (o + 7) & ~7;
-    l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;
+    l.off_win = o;    o += (win_lds && lds_win_in_lds(n)) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
     return l;
 }
@@ -210,9 +210,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
     // requested when it starts and the other waves of the SIMD cover the latency
     constexpr bool LATE_PF = WAVES > 8 || SP_X_LATEPF;
+    // 3 waves per SIMD at n = 1024 (one wave per frame): the next frame's raw samples travel HBM -> LDS by LDS-DMA
+    // (global_load_lds_dwordx4: no registers) into the frame's exchange buffer, which is idle once the first exchange has been
+    // read back (the second one is a register transpose); the taper comes from L2 at the top of a frame.
+    constexpr bool DMA = WAVES > 8 && LOG2N == 10 && !CH && (PFB == 8 || PFB == 4 || PFB == 2 || PFB == 1);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Layout lay = layout(N, a.lut_len, group_frames, kThreads, EDGES_LDS);
+    const Layout lay = layout(N, a.lut_len, group_frames, kThreads, EDGES_LDS, WAVES == 8);
     double *s_xch = (double *)smem;
     double2 *s_tw = (double2 *)(smem + lay.off_tw);
     const double *edge_g = EDGES_LDS ? (const double *)(smem + lay.off_gedge) : a.gray_edge;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 
     constexpr bool PF = PFB != 0;
     const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
-    const int rounds = group_frames / FPB;
+    const int rounds = (group_frames + FPB - 1) / FPB;   // the last round may fill only part of the slots (12 waves, 32 frames)
     uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
     int raw_back = 0;
     auto request = [&](int xq) {
@@ -248,6 +252,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
         }
     };
+    // LDS-DMA of frame xq into this wave's exchange buffer: 16-byte granules from the granule that holds the frame's first byte;
+    // dma_off is that byte's offset in its granule (the decode reads from there)
+    int dma_off = 0;
+    auto dma_request = [&](int xq) {
+        if constexpr (DMA) {
+            const int xc = xq < a.width ? xq : a.width - 1;
+            const int64_t byte0 = (int64_t)frame_start(a.stride, xc) * PFB;
+            dma_off = (int)(byte0 & 15);
+            const uint8_t *src = a.bytes + (byte0 - dma_off) + lane * 16;
+            const int total = N * PFB + dma_off;
+            constexpr int CHUNKS = (N * PFB + 15 + 1023) / 1024;
+#pragma unroll
+            for (int j = 0; j < CHUNKS; j++) {
+                if (j * 1024 + lane * 16 < total)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
+                                                     (__attribute__((address_space(3))) void *)((unsigned char *)xbuf + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request((xcd * chunk + lane_in_xcd) * group_frames + fs);
     if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
 
     {
@@ -287,11 +311,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
     }
 
-    constexpr bool WIN_LDS = lds_win_in_lds(N);
+    constexpr bool WIN_LDS = lds_win_in_lds(N) && !DMA;
     double *s_win = (double *)(smem + lay.off_win);
     const double *const wbase = s_win + tl;   // stored as the threads read it: entry e*T + tl = taper[rev4(e)*T + rev(tl)]
-    double win_reg[WIN_LDS ? 1 : 16];
-    if constexpr (WIN_LDS) {
+    double win_reg[(WIN_LDS || DMA) ? 1 : 16];
+    if constexpr (DMA) {
+        // nothing resident: 16 loads per frame from L2
+    } else if constexpr (WIN_LDS) {
         for (int i = tid; i < N; i += kThreads) {
             const int e = i / T, t = i % T;
             s_win[i] = a.window[rev4(e) * T + (int)(__brev((unsigned)t) >> (32 - (LOG2N - 4)))];
@@ -314,13 +340,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
     uint32_t pf_word = 0;
     // epilogue constants (sp_host.cpp build_thresholds): t = a + b*log2(|X|^2), already lowered by the margin
-    const float g_a = a.g2_a, g_b = a.g2_b, g_thr = a.g2_thr, g_m = a.g2_m;
-    const float c_a = a.c2_a, c_b = a.c2_b, c_thr = a.c2_thr, c_m = a.c2_m, c_lo = a.c2_lo, c_hi = a.c2_hi;
+    const float g_a = a.g2_a, g_b = a.g2_b, g_m = a.g2_m;
+    const float c_a = a.c2_a, c_b = a.c2_b, c_m = a.c2_m, c_lo = a.c2_lo, c_hi = a.c2_hi;
+    const float thr = fminf(a.g2_thr, a.c2_thr);
     // clamp bounds of the colour value: clipped pixels sit in the middle of the first / last step, far from the risky zone
     const float g_lo = 0.5f, g_hi = (float)cmax + 0.5f;
     const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
+    const bool nt_rows = group_frames >= 32;
     auto drain = [&](const int x0, const int part, const int nparts) {
         if (part == 0 && tid < group_frames) {
             if (x0 + tid < a.width) {
@@ -388,9 +416,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #ifdef SP_ABL_NOSTORE
                                 if (px[u][j][0] != 0x12345678u) continue;
 #endif
-                                // written once, never read by this kernel: non-temporal, so the image does not displace the
-                                // capture's lines in L2 (measured: 2.5 % of the kernel)
-                                store_nt(a.rgba + off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                                // written once, never read by this kernel: non-temporal where a group's row segments are whole
+                                // 128-byte lines, so that the image does not displace the capture's lines in L2 (measured: 2.5 % of the
+                                // kernel at n = 1024); shorter segments (large n) are pieces of lines that L2 has to merge with the
+                                // neighbouring groups' pieces (non-temporal there doubled the HBM traffic)
+                                if (nt_rows) store_nt(a.rgba + off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                                else *(uint4 *)(a.rgba + off) = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             }
                         }
                         continue;
@@ -452,6 +483,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #endif
             const int fr = r * FPB + fs;
             const int xr = x0 + fr;
+            if (fr >= group_frames) continue;   // a slot without a frame in the group's last round (its next frame is already requested)
             const bool live = xr < a.width;
             const int x = live ? xr : a.width - 1;
             const int64_t start = frame_start(a.stride, x);
@@ -459,10 +491,49 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             double re[16], im[16];
             double win[16];
             bool nonfinite = true;   // wave-uniform
+            if constexpr (DMA) {
+                // re-read every frame (L2 hits); the offset is hidden from the optimiser so that it does not keep the 16 values in
+                // registers across the frame loop
+                unsigned w_off = 0;
+                asm volatile("" : "+s"(w_off));
+                const char *wp = (const char *)(a.window + w_off);
+                // one per-lane offset register; the 16 entries are T*8 bytes apart, addressed by instruction offsets around the
+                // middle one (the offset field of a global load is 13 bits, signed)
+                unsigned w_lane = (unsigned)sidx_pf * 8u + 15u * T * 4u;
+                asm volatile("" : "+v"(w_lane));
 #pragma unroll
-            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
-            const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
-            if constexpr (PF && LATE_PF) request(xr);
+                for (int e = 0; e < 16; e++) win[e] = *(const double *)(wp + w_lane + (rev4(e) * T * 8 - 15 * T * 4));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
+            }
+            // the frame this slot processes next: the same slot one round on, or its frame in the workgroup's next group
+            const int xn = (r + 1 < rounds && fr + FPB < group_frames) ? xr + FPB
+                                                                         : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
+            if constexpr (DMA) {
+                // the samples are in the exchange buffer once the wave's LDS-DMA operations have landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // one address register (this lane's sample of the first run), instruction offsets for the other 15 runs
+                unsigned raw_lane = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)xbuf + (unsigned)dma_off
+                                    + (unsigned)sidx_pf * PFB;
+                asm volatile("" : "+v"(raw_lane));
+                const __attribute__((address_space(3))) unsigned char *rawb = (const __attribute__((address_space(3))) unsigned char *)(size_t)raw_lane;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int off = rev4(e) * T * PFB;
+                    if constexpr (PFB == 8) {
+                        const unsigned long long w = *(const __attribute__((address_space(3))) unsigned long long *)(rawb + off);
+                        raw_lo[e] = (uint32_t)w;
+                        raw_hi[e] = (uint32_t)(w >> 32);
+                    } else if constexpr (PFB == 4) {
+                        raw_lo[e] = *(const __attribute__((address_space(3))) uint32_t *)(rawb + off);
+                    } else if constexpr (PFB == 2) {
+                        raw_lo[e] = *(const __attribute__((address_space(3))) uint16_t *)(rawb + off);
+                    } else {
+                        raw_lo[e] = rawb[off];
+                    }
+                }
+            } else if constexpr (PF && LATE_PF) request(xr);
             if constexpr (PF) {
                 if constexpr (PFB == 1) {
                     if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
@@ -529,6 +600,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                 exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
                 exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
                 exchange_wait(re, im);
+                if constexpr (DMA) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the buffer has returned
+                    if (xn >= 0) dma_request(xn);                       // in flight until the next frame starts
+                }
                 SP_STAMP(1)   // (first write-out slice,) first pass, first exchange
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
@@ -640,6 +715,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
                     float tg[4], tc[4];
                     int gi[4], cell[4];
                     bool risky[4];
+                    float worst = 0.0f;   // largest fractional part of the batch, either scale
                     // written stage by stage: the four chains are independent, and every step of a chain waits on the one before
                     float l2[4];
 #pragma unroll
@@ -677,13 +753,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
 #ifndef SP_ABL_NORISKY
-                        risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < g_thr) || !(__builtin_amdgcn_fractf(tc[k]) < c_thr);
-#else
-                        risky[k] = false;
+                        // (the clamps have turned a NaN into a bound, so the fractional parts are numbers; one threshold, the
+                        // smaller of the two, serves both scales)
+                        worst = fmaxf(fmaxf(worst, __builtin_amdgcn_fractf(tg[k])), __builtin_amdgcn_fractf(tc[k]));   // one v_max3_f32
 #endif
                         cell[k] += gi[k];
                     }
-                    if (__builtin_expect(__ballot(risky[0] || risky[1] || risky[2] || risky[3]) != 0ull, 0)) {
+                    if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < thr) || !(__builtin_amdgcn_fractf(tc[k]) < thr);
 #ifdef SP_STAMPS
                         stamp_slow++;
 #endif
@@ -777,7 +856,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #ifndef SP_X_EDGES_GLOBAL
 #define SP_X_EDGES_GLOBAL 0
 #endif
-__host__ __device__ inline constexpr int frames_waves(int log2n) { return log2n <= 10 ? SP_FRAMES_WAVES : 8; }
+__host__ __device__ inline constexpr int frames_waves(int log2n, bool channel_mode, int prefetch)
+{
+    return (log2n == 10 && !channel_mode && (prefetch == 8 || prefetch == 4 || prefetch == 2 || prefetch == 1)) ? SP_FRAMES_WAVES : 8;
+}
 
 // Per-n launchers, one translation unit each (sp_inst_frames.hip compiled once per LOG2N).
 template <int L>
@@ -811,7 +893,7 @@ int launch_frames_n<SP_INST_FRAMES_LOG2N>(const FrameArgs &a, int format, const 
                                    int prefetch, int device, hipStream_t stream)
 {
     constexpr int L = SP_INST_FRAMES_LOG2N;
-#define SP_V(C, P) return launch_variant<L, C, P, frames_waves(L), frames_waves(L) == 8 && !SP_X_EDGES_GLOBAL>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
+#define SP_V(C, P) return launch_variant<L, C, P, frames_waves(L, C, P), frames_waves(L, C, P) == 8 && !SP_X_EDGES_GLOBAL>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
 #define SP_CH(C)                                                                                              \
     switch (prefetch) {                                                                                       \
     case 8: SP_V(C, 8) case 4: SP_V(C, 4) case 3: SP_V(C, 3) case 2: SP_V(C, 2) case 1: SP_V(C, 1) default: SP_V(C, 0) \
@@ -825,7 +907,9 @@ int launch_frames_n<SP_INST_FRAMES_LOG2N>(const FrameArgs &a, int format, const 
 // Host-side launch.  Returns SP_OK or SP_ERR_UNSUPPORTED.
 inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw, int cu_count, int device, hipStream_t stream)
 {
-    const int waves = frames_waves(a.levels);
+    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;
+    if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
+    const int waves = frames_waves(a.levels, a.channel_mode != 0, prefetch);
     if (!frames_kernel_supports(a.n, waves) || a.lut_len > kLdsMaxLut || a.lut_len < 2) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
 #ifndef SP_X_WANT
@@ -833,14 +917,13 @@ inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw
 #endif
     int want = SP_X_WANT;
     while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
-    const int gf = group_frames_for(n, want, waves * 64);
+    // (12 waves at n = 1024: 32-frame groups in three rounds, the last one with 8 of the 12 slots)
+    const int gf = waves > 8 && want >= 32 ? 32 : group_frames_for(n, want, waves * 64);
     const int groups = (a.width + gf - 1) / gf;
-    const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL);
+    const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL, waves == 8);
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
     int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;
-    int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;
-    if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
     switch (a.levels) {
 #define SP_L(L) case L: return launch_frames_n<L>(a, format, stage_tw, grid, lay.total, gf, groups, prefetch, device, stream);
         SP_L(6) SP_L(7) SP_L(8) SP_L(9) SP_L(10) SP_L(11) SP_L(12) SP_L(13)

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Collects, on the GPU box, what profiles/ holds per BASELINE config: rocprofv3 kernel-trace summary, PMC summary (separate passes),
+# HBM traffic per launch and the bench line itself.
+#   tools/collect_profiles.sh <tag e.g. r02> "<configs e.g. cfg2 cfg1 cfg3 cfg4 cfg5>"
+# Results land in gpurun_out/profiles_<tag>/ (copy the files to profiles/ and commit them).
+TAG=$1; CFGS=${2:-"cfg2"}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for C in $CFGS; do
+  STEPS="--steps 400 --warmup 100"
+  # 1. counters, one pass per counter group (tools/prof_pmc.sh), then the traffic figure bench.py quotes
+  $ROOT/tools/prof_pmc.sh ${TAG}_$C --config $C $STEPS > /dev/null 2>&1
+  cp $ROOT/gpurun_out/pmc_${TAG}_${C}_summary.txt $OUT/${TAG}_${C}_pmc_summary.txt
+  rm -rf $ROOT/gpurun_out/pmc_${TAG}_${C}   # the raw per-dispatch CSVs are large
+  python3 - "$OUT/${TAG}_${C}_pmc_summary.txt" "$C" > $OUT/${TAG}_${C}_traffic.json <<'PY'
+import json, re, sys
+txt = open(sys.argv[1]).read()
+blk = [b for b in txt.split("== ") if "k_frames" in b or "k_lds_r16" in b or "k_scratch" in b]
+blk = max(blk, key=lambda b: float(re.search(r"SQ_WAVE_CYCLES\s+n=\s*\d+\s+mean=\s*([\d.]+)", b).group(1)) if "SQ_WAVE_CYCLES" in b else 0)
+name = blk.splitlines()[0]
+g = lambda k: float(re.search(k + r"\s+n=\s*\d+\s+mean=\s*([\d.]+)", blk).group(1))
+fetch, write = g("FETCH_SIZE"), g("WRITE_SIZE")
+print(json.dumps({"config": sys.argv[2], "kernel": name,
+  "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_pmc.sh), mean over the second half of the launches",
+  "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "fetch_correction": 2.0,
+  "correction_note": "gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM): doubled here; WRITE_SIZE is exact for 16-byte streaming stores",
+  "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0}, indent=1))
+PY
+  mkdir -p $ROOT/profiles && cp $OUT/${TAG}_${C}_traffic.json $ROOT/profiles/${TAG}_${C}_traffic.json
+  # 2. kernel durations
+  rm -rf /tmp/kt_$C
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$C -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --config $C > /tmp/kt_$C.log 2>&1
+  cp $(find /tmp/kt_$C -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${C}_kernel_stats.csv
+  # 3. the bench line (un-profiled); the CPU baseline and the Node drop-in leg ride with the headline config
+  if [ "$C" = "cfg2" ]; then python3 $ROOT/bench.py --config $C > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err
+  else python3 $ROOT/bench.py --config $C --no-e2e > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err; fi
+  tail -c 600 $OUT/${TAG}_${C}_bench.json; echo
+done
