@@ -18,6 +18,8 @@
 // Everything else (input prefetch, exchange buffer, tile and write-out, per-frame extremes) follows k_lds_r16.
 #pragma once
 
+#include <cstdio>
+
 #include "sp_kernel_lds.h"
 
 namespace spk2 {
@@ -191,7 +193,7 @@ __device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_
 #endif
 
 template <int LOG2N, bool CH, int PFB, int WAVES, bool EDGES_LDS>
-__global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                        const int group_frames, const int groups)
 {
     constexpr int kThreads = WAVES * 64;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Layout lay = layout(N, a.lut_len, group_frames, kThreads, EDGES_LDS, WAVES == 8);
+    static_assert(WAVES == 4 || WAVES == 8 || WAVES == 12, "workgroup shapes: 4 (two per CU), 8, 12 waves");
     double *s_xch = (double *)smem;
     double2 *s_tw = (double2 *)(smem + lay.off_tw);
     const double *edge_g = EDGES_LDS ? (const double *)(smem + lay.off_gedge) : a.gray_edge;
@@ -311,11 +314,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
     }
 
-    constexpr bool WIN_LDS = lds_win_in_lds(N) && !DMA;
+    // two 4-wave workgroups per CU (80 KiB of LDS each): the taper does not fit and is re-read from L2 like in the DMA variant
+    constexpr bool WIN_GLOBAL = DMA || (WAVES == 4 && lds_win_in_lds(N));
+    constexpr bool WIN_LDS = lds_win_in_lds(N) && !WIN_GLOBAL;
     double *s_win = (double *)(smem + lay.off_win);
     const double *const wbase = s_win + tl;   // stored as the threads read it: entry e*T + tl = taper[rev4(e)*T + rev(tl)]
-    double win_reg[(WIN_LDS || DMA) ? 1 : 16];
-    if constexpr (DMA) {
+    double win_reg[(WIN_LDS || WIN_GLOBAL) ? 1 : 16];
+    if constexpr (WIN_GLOBAL) {
         // nothing resident: 16 loads per frame from L2
     } else if constexpr (WIN_LDS) {
         for (int i = tid; i < N; i += kThreads) {
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
             double re[16], im[16];
             double win[16];
             bool nonfinite = true;   // wave-uniform
-            if constexpr (DMA) {
+            if constexpr (WIN_GLOBAL) {
                 // re-read every frame (L2 hits); the offset is hidden from the optimiser so that it does not keep the 16 values in
                 // registers across the frame loop
                 unsigned w_off = 0;
@@ -858,6 +863,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames(const FrameArgs a, const 
 #endif
 __host__ __device__ inline constexpr int frames_waves(int log2n, bool channel_mode, int prefetch)
 {
+    if (SP_FRAMES_WAVES == 4) return (log2n == 10 && !channel_mode && prefetch != 0) ? 4 : 8;
     return (log2n == 10 && !channel_mode && (prefetch == 8 || prefetch == 4 || prefetch == 2 || prefetch == 1)) ? SP_FRAMES_WAVES : 8;
 }
 
@@ -883,6 +889,18 @@ inline int launch_variant(const FrameArgs &a, int format, const double2 *stage_t
             return SP_ERR_HIP;
         if (device >= 0 && device < kMaxDevices) attr_set[device] = true;
     }
+#ifdef SP_DEBUG_OCC
+    {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_frames<L, C, P, W, E>, W * 64, (size_t)lds_bytes);
+            fprintf(stderr, "k_frames<%d,%d,%d,%d,%d>: %d blocks per CU at %d bytes of LDS, grid %d, group %d frames\n", L, (int)C, P, W, (int)E, nb,
+                    lds_bytes, grid, gf);
+        }
+    }
+#endif
     hipLaunchKernelGGL((k_frames<L, C, P, W, E>), dim3((unsigned)grid), dim3(W * 64), (size_t)lds_bytes, stream, a, format, stage_tw, gf,
                        groups);
     return SP_OK;
@@ -917,12 +935,15 @@ inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw
 #endif
     int want = SP_X_WANT;
     while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
-    // (12 waves at n = 1024: 32-frame groups in three rounds, the last one with 8 of the 12 slots)
+    // (12 waves at n = 1024: 32-frame groups in three rounds, the last one with 8 of the 12 slots;
+    //  4 waves: two workgroups per CU, 80 KiB of LDS each: 16-frame groups)
+    if (waves == 4 && want > 16) want = 16;
+    const int wg_per_cu = waves == 4 ? 2 : 1;
     const int gf = waves > 8 && want >= 32 ? 32 : group_frames_for(n, want, waves * 64);
     const int groups = (a.width + gf - 1) / gf;
     const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL, waves == 8);
-    if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
-    int grid = groups < cu_count ? groups : cu_count;
+    if (lay.total > 160 * 1024 / wg_per_cu) return SP_ERR_UNSUPPORTED;
+    int grid = groups < cu_count * wg_per_cu ? groups : cu_count * wg_per_cu;
     grid = (grid + 7) & ~7;
     switch (a.levels) {
 #define SP_L(L) case L: return launch_frames_n<L>(a, format, stage_tw, grid, lay.total, gf, groups, prefetch, device, stream);
