@@ -185,6 +185,9 @@ int sp_plan_force_kernel(sp_plan *plan, int32_t which);
  */
 int sp_host_alloc(size_t nbytes, void **ptr);
 void sp_host_free(void *ptr);
+/* Page-locks (and later releases) memory the caller owns, e.g. a reply block that is being recycled. */
+int sp_host_register(void *ptr, size_t nbytes);
+void sp_host_unregister(void *ptr);
 
 /* Device memory helpers so that non-HIP hosts (Node, ctypes) can keep operands resident. */
 int sp_device_alloc(sp_context *ctx, size_t nbytes, void **d_ptr);

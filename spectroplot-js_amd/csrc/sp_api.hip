@@ -62,6 +62,10 @@ struct sp_context {
     DeviceBuffer scratch;        // scratch kernel slabs
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small;
+    // sp_render's copy streams and events: the image goes back to the host chunk by chunk while later chunks still arrive
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    static constexpr int kMaxChunks = 8;
+    hipEvent_t ev_arrived[kMaxChunks] = {}, ev_rendered[kMaxChunks] = {};
     sp_plan *cached_plan = nullptr;
     // sp_render_named: the names and numbers the cached plan was built from (empty: the cached plan came from arrays)
     std::string named_format, named_window, named_cmap;
@@ -244,6 +248,17 @@ extern "C" void sp_host_free(void *ptr)
     if (ptr) (void)hipHostFree(ptr);
 }
 
+extern "C" int sp_host_register(void *ptr, size_t nbytes)
+{
+    if (!ptr || !nbytes) return SP_ERR_INVALID_ARG;
+    return hipHostRegister(ptr, nbytes, hipHostRegisterDefault) == hipSuccess ? SP_OK : SP_ERR_HIP;
+}
+
+extern "C" void sp_host_unregister(void *ptr)
+{
+    if (ptr) (void)hipHostUnregister(ptr);
+}
+
 // ------------------------------------------------------------------------------------------------- contexts
 
 extern "C" int sp_device_count(int32_t *count)
@@ -291,6 +306,12 @@ extern "C" void sp_context_destroy(sp_context *ctx)
     ctx->render_small.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < sp_context::kMaxChunks; k++) {
+        if (ctx->ev_arrived[k]) (void)hipEventDestroy(ctx->ev_arrived[k]);
+        if (ctx->ev_rendered[k]) (void)hipEventDestroy(ctx->ev_rendered[k]);
+    }
+    if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+    if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -580,7 +601,11 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
     }
 }
 
-extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *out)
+// The frame loop over frames [x_begin, x_end) of a width-frame image.  `first` prepares the context's workspace and accumulators,
+// `last` queues the finish kernel (gauges, histograms, dBfs range of the whole request).  sp_plan_execute is the whole range in one
+// launch; sp_render walks the image in chunks so that the copies to and from the host overlap.
+static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, int32_t x_begin, int32_t x_end, bool first,
+                              bool last, const sp_reply *out)
 {
     if (!plan || !out) return SP_ERR_INVALID_ARG;
     sp_context *ctx = plan->ctx;
@@ -639,7 +664,7 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     const bool fresh_partial = ctx->partial.cap < acc_bytes;
     rc = ctx->partial.reserve(acc_bytes);
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
-    if (fresh_partial || ctx->acc_dirty) {
+    if (first && (fresh_partial || ctx->acc_dirty)) {
         static const unsigned long long mm_init[2] = {0x7ff0000000000000ull, 0ull};           // +inf, 0
         SP_HIP(ctx, hipMemsetAsync(ctx->partial.p, 0, ctx->partial.cap, s));
         SP_HIP(ctx, hipMemcpyAsync((char *)ctx->partial.p + 16, mm_init, sizeof mm_init, hipMemcpyHostToDevice, s));
@@ -659,7 +684,8 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     a.waterfall = plan->req.waterfall ? 1 : 0;
     a.lut_len = plan->req.lut_len;
     a.in_bounds = in_bounds ? 1 : 0;
-    a.frame0 = 0;
+    a.frame0 = x_begin;
+    a.x_end = x_end;
     a.sample_width = f.width;
     a.window = plan->d_window;
     a.cos_t = plan->d_cos;
@@ -714,7 +740,7 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
     } else {
         // scratch slabs: one per workgroup, capped at 256 MiB
         long long blocks = (256ll << 20) / (16ll * n);
-        if (blocks > width) blocks = width;
+        if (blocks > x_end - x_begin) blocks = x_end - x_begin;
         if (blocks > 4 * ctx->cu_count) blocks = 4 * ctx->cu_count;
         if (blocks < 1) blocks = 1;
         rc = ctx->scratch.reserve((size_t)blocks * 2 * (size_t)n * sizeof(double));
@@ -731,6 +757,8 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
         SP_HIP(ctx, hipEventRecord(ctx->ev1, s));
         ctx->timed = true;
     }
+
+    if (!last) return SP_OK;
 
     spk::FinishArgs fa{};
     fa.bytes = a.bytes;
@@ -780,6 +808,11 @@ extern "C" int sp_debug_read_stamps(sp_context *ctx, unsigned long long *dst, si
     return SP_OK;
 }
 #endif
+
+extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *out)
+{
+    return plan_execute_range(plan, d_bytes, nbytes, width, 0, width < 0 ? 0 : width, true, true, out);
+}
 
 // ------------------------------------------------------------------------------------------------- merge of slice replies
 
@@ -867,10 +900,6 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     double *d_mm = (double *)(d_cb + SP_CB_HIST_SIZE);
     uint8_t *d_g = (uint8_t *)(d_mm + 2);
 
-    hipError_t e = hipSuccess;
-    if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(small.p, 0, small_u64 * 8, s);
-    if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
     sp_reply d{};
     d.rgba = reply->rgba ? (uint8_t *)ctx->out_rgba.p : nullptr;
     d.gauge_mins = d_g;
@@ -879,15 +908,85 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     d.c_hist = d_c;
     d.cb_hist = d_cb;
     d.dbfs_minmax = d_mm;
-    rc = sp_plan_execute(plan, ctx->in_bytes.p, nbytes, width, &d);
-    if (rc) {
-        (void)hipStreamSynchronize(s);
-        return rc;
+
+    // Large requests are rendered in chunks of frames: chunk k's samples travel to the device while chunk k-1 is rendered and
+    // chunk k-2's part of the image travels back (PCIe is full duplex; the kernels are a few per cent of the copies).  Chunks end
+    // on multiples of 32 frames (whole write-out groups); a chunk needs the samples up to the end of its last frame.
+    const spfmt::Format f = spfmt::describe(req->format);
+    const double sample_count = (double)nbytes / (double)f.width;
+    const double stride = width > 1 ? (sample_count - (double)req->n) / (double)(width - 1) : 0.0;
+    int chunks = 1;
+    if (reply->rgba && width >= 1024 && nbytes + rgba_bytes >= ((size_t)16 << 20) && stride >= 0.0 && std::isfinite(stride)
+        && 0.5 + stride * (double)(width - 1) < 2147483000.0)
+        chunks = width >= 8192 ? 8 : 4;
+    hipError_t e = hipSuccess;
+    if (chunks > 1) {
+        if (!ctx->copy_in) e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
+        if (e == hipSuccess && !ctx->copy_out) e = hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking);
+        for (int k = 0; k < chunks && e == hipSuccess; k++) {
+            if (!ctx->ev_arrived[k]) e = hipEventCreateWithFlags(&ctx->ev_arrived[k], hipEventDisableTiming);
+            if (e == hipSuccess && !ctx->ev_rendered[k]) e = hipEventCreateWithFlags(&ctx->ev_rendered[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return hip_fail(ctx, e, "sp_render streams");
+    }
+    e = hipMemsetAsync(small.p, 0, small_u64 * 8, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
+    if (chunks == 1) {
+        if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
+        rc = sp_plan_execute(plan, ctx->in_bytes.p, nbytes, width, &d);
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
+    } else {
+        size_t sent = 0;
+        int32_t x0 = 0;
+        for (int k = 0; k < chunks; k++) {
+            const int32_t x1 = k + 1 == chunks ? width : (int32_t)(((int64_t)width * (k + 1) / chunks) & ~(int64_t)31);
+            size_t need = nbytes;
+            if (k + 1 < chunks) {
+                const int64_t last_start = spjs::to_int32(0.5 + stride * (double)(x1 - 1));          // worker.js:72
+                need = (size_t)(last_start + req->n) * (size_t)f.width;
+                if (need > nbytes) need = nbytes;
+            }
+            if (need > sent) {
+                e = hipMemcpyAsync((char *)ctx->in_bytes.p + sent, bytes + sent, need - sent, hipMemcpyHostToDevice, ctx->copy_in);
+                sent = need;
+            }
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_arrived[k], ctx->copy_in);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, ctx->ev_arrived[k], 0);
+            if (e != hipSuccess) break;
+            rc = plan_execute_range(plan, ctx->in_bytes.p, nbytes, width, x0, x1, k == 0, k + 1 == chunks, &d);
+            if (rc) break;
+            e = hipEventRecord(ctx->ev_rendered[k], s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_out, ctx->ev_rendered[k], 0);
+            if (e != hipSuccess) break;
+            if (x1 > x0) {
+                if (req->waterfall) {   // rows width-1-x: the chunk is one contiguous band of rows
+                    const size_t off = 4 * n * (size_t)(width - x1);
+                    e = hipMemcpyAsync(reply->rgba + off, (char *)ctx->out_rgba.p + off, 4 * n * (size_t)(x1 - x0), hipMemcpyDeviceToHost,
+                                       ctx->copy_out);
+                } else {                // columns x0 .. x1-1 of every row
+                    e = hipMemcpy2DAsync(reply->rgba + 4 * (size_t)x0, 4 * W, (char *)ctx->out_rgba.p + 4 * (size_t)x0, 4 * W,
+                                         4 * (size_t)(x1 - x0), n, hipMemcpyDeviceToHost, ctx->copy_out);
+                }
+                if (e != hipSuccess) break;
+            }
+            x0 = x1;
+        }
+        if (rc || e != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->copy_in);
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(ctx->copy_out);
+            ctx->acc_dirty = true;
+            return rc ? rc : hip_fail(ctx, e, "sp_render chunk");
+        }
     }
     auto down = [&](void *dst, const void *src, size_t bytes_) {
         if (dst && bytes_ && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, s);
     };
-    down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
+    if (chunks == 1) down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
     down(reply->gauge_mins, d.gauge_mins, W);
     down(reply->gauge_maxs, d.gauge_maxs, W);
     down(reply->gauge_amps, d.gauge_amps, W);
@@ -895,6 +994,10 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     down(reply->cb_hist, d_cb, SP_CB_HIST_SIZE * 8);
     down(reply->dbfs_minmax, d_mm, 16);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (chunks > 1) {
+        const hipError_t e2 = hipStreamSynchronize(ctx->copy_out);
+        if (e == hipSuccess) e = e2;
+    }
     if (e != hipSuccess) return hip_fail(ctx, e, "sp_render download");
     return SP_OK;
 }

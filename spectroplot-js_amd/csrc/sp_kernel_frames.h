@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     int raw_back = 0;
     auto request = [&](int xq) {
         if constexpr (PF) {
-            const int xc = xq < a.width ? xq : a.width - 1;
+            const int xc = xq < a.x_end ? xq : a.x_end - 1;
             const int64_t st = frame_start(a.stride, xc);
             if constexpr (PFB == 3) raw_back = (st + N) * 3 + 1 > a.nbytes ? 1 : 0;
             issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     int dma_off = 0;
     auto dma_request = [&](int xq) {
         if constexpr (DMA) {
-            const int xc = xq < a.width ? xq : a.width - 1;
+            const int xc = xq < a.x_end ? xq : a.x_end - 1;
             const int64_t byte0 = (int64_t)frame_start(a.stride, xc) * PFB;
             dma_off = (int)(byte0 & 15);
             const uint8_t *src = a.bytes + (byte0 - dma_off) + lane * 16;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
         }
     };
-    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request((xcd * chunk + lane_in_xcd) * group_frames + fs);
-    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
+    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs);
+    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs);
 
     {
         // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const bool nt_rows = group_frames >= 32;
     auto drain = [&](const int x0, const int part, const int nparts) {
         if (part == 0 && tid < group_frames) {
-            if (x0 + tid < a.width) {
+            if (x0 + tid < a.x_end) {
                 unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
 #pragma unroll
                 for (int k = 0; k < MMS; k++) {
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         const int itc = it < items ? it : it0;
                         const int e4 = itc & 3, fq = (itc >> 2) % quads, tq = (itc >> 2) / quads;   // tq: thread of the frame
                         i0v[u] = tq + 4 * e4 * T;
-                        xav[u] = it < items ? x0 + fq * 4 : a.width;
+                        xav[u] = it < items ? x0 + fq * 4 : a.x_end;
 #pragma unroll
                         for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + tq * 16 + e4 * 4);
                     }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
                             const int xa = xav[u];
-                            if (xa >= a.width) continue;
+                            if (xa >= a.x_end) continue;
                             const unsigned y0 = (unsigned)(N / 2 - i0v[u]) & (N - 1);
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int xa = xav[u];
-                        if (xa >= a.width) continue;
+                        if (xa >= a.x_end) continue;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const int i = i0v[u] + j * T;
@@ -443,12 +443,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifdef SP_ABL_NOSTORE
                             if (px[u][j][0] != 0x12345678u) continue;
 #endif
-                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                            if (xa + 3 < a.x_end && (((size_t)dst & 15) == 0)) {
                                 *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < 4; k++)
-                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
+                                    if (xa + k < a.x_end) ((uint32_t *)dst)[k] = px[u][j][k];
                             }
                         }
                     }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 for (int it = tid + part * kThreads; it < items; it += nparts * kThreads) {
                     const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
                     const int xa = x0 + f;
-                    if (xa >= a.width) continue;
+                    if (xa >= a.x_end) continue;
                     const unsigned char *row = s_tile + f * tile_pitch;
                     uint32_t px[4];
 #pragma unroll
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const unsigned long long stamp_begin = stamp_last;
 #endif
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
-        const int x0 = g * group_frames;
+        const int x0 = a.frame0 + g * group_frames;
         for (int r = 0; r < rounds; r++) {
 #ifdef SP_X_STAGGER
             // experiment: the second wave of every SIMD starts each group late, so that the two are in different phases
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             const int fr = r * FPB + fs;
             const int xr = x0 + fr;
             if (fr >= group_frames) continue;   // a slot without a frame in the group's last round (its next frame is already requested)
-            const bool live = xr < a.width;
-            const int x = live ? xr : a.width - 1;
+            const bool live = xr < a.x_end;
+            const int x = live ? xr : a.x_end - 1;
             const int64_t start = frame_start(a.stride, x);
 
             double re[16], im[16];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
             // the frame this slot processes next: the same slot one round on, or its frame in the workgroup's next group
             const int xn = (r + 1 < rounds && fr + FPB < group_frames) ? xr + FPB
-                                                                         : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
+                                                                         : (g + per_xcd < g_end ? a.frame0 + (g + per_xcd) * group_frames + fs : -1);
             if constexpr (DMA) {
                 // the samples are in the exchange buffer once the wave's LDS-DMA operations have landed
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 if (!LATE_PF && xn >= 0) request(xn);           // in flight during this frame's butterflies
             } else {
                 asm volatile("" ::"v"(pf_word));
-                if (a.in_bounds && xn >= 0 && xn < a.width) {
+                if (a.in_bounds && xn >= 0 && xn < a.x_end) {
                     const int lines = (N * a.sample_width + 127) >> 7;
                     const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
                     for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
@@ -934,13 +934,13 @@ inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw
 #define SP_X_WANT 32
 #endif
     int want = SP_X_WANT;
-    while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
+    while (want > 4 && (a.x_end - a.frame0 + want - 1) / want < 2 * cu_count) want >>= 1;
     // (12 waves at n = 1024: 32-frame groups in three rounds, the last one with 8 of the 12 slots;
     //  4 waves: two workgroups per CU, 80 KiB of LDS each: 16-frame groups)
     if (waves == 4 && want > 16) want = 16;
     const int wg_per_cu = waves == 4 ? 2 : 1;
     const int gf = waves > 8 && want >= 32 ? 32 : group_frames_for(n, want, waves * 64);
-    const int groups = (a.width + gf - 1) / gf;
+    const int groups = (a.x_end - a.frame0 + gf - 1) / gf;
     const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL, waves == 8);
     if (lay.total > 160 * 1024 / wg_per_cu) return SP_ERR_UNSUPPORTED;
     int grid = groups < cu_count * wg_per_cu ? groups : cu_count * wg_per_cu;

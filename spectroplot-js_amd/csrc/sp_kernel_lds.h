@@ -448,14 +448,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     int raw_back = 0;   // 3-byte samples: 1 if the words now in raw_lo were fetched one byte low (frame ending with the buffer)
     auto request = [&](int xq) {
         if constexpr (PF) {
-        const int xc = xq < a.width ? xq : a.width - 1;
+        const int xc = xq < a.x_end ? xq : a.x_end - 1;
         const int64_t st = frame_start(a.stride, xc);
         if constexpr (PFB == 3) raw_back = (st + N) * 3 + 1 > a.nbytes ? 1 : 0;
         issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
         }
     };
     // the first frame's samples are requested before the tables: one HBM round trip for both
-    if (PF && xcd * chunk + lane_in_xcd < g_end) request((xcd * chunk + lane_in_xcd) * group_frames + fs);
+    if (PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs);
 
     {
         // request tables -> LDS: every global load is issued before the first LDS store, so the prologue costs one memory
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     // into HBM while the SIMDs compute (the extremes go with slice 0)
     auto drain = [&](const int x0, const int part, const int nparts) {
         if (part == 0 && tid < group_frames) {
-            if (x0 + tid < a.width) {
+            if (x0 + tid < a.x_end) {
                 unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
 #pragma unroll
                 for (int k = 0; k < MMS; k++) {
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         const int itc = it < items ? it : it0;
                         const int fq = itc % quads, bq = itc / quads;
                         i0v[u] = bq * 4;
-                        xav[u] = it < items ? x0 + fq * 4 : a.width;      // past the image: nothing is stored
+                        xav[u] = it < items ? x0 + fq * 4 : a.x_end;      // past the image: nothing is stored
 #pragma unroll
                         for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + i0v[u]);
                     }
@@ -578,18 +578,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int xa = xav[u];
-                        if (xa >= a.width) continue;
+                        if (xa >= a.x_end) continue;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const int i = i0v[u] + j;
                             const int y = (N / 2 - i) & (N - 1);
                             uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
-                            if (xa + 3 < a.width && (((size_t)dst & 15) == 0)) {
+                            if (xa + 3 < a.x_end && (((size_t)dst & 15) == 0)) {
                                 *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < 4; k++)
-                                    if (xa + k < a.width) ((uint32_t *)dst)[k] = px[u][j][k];
+                                    if (xa + k < a.x_end) ((uint32_t *)dst)[k] = px[u][j][k];
                             }
                         }
                     }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 for (int it = tid + part * kLdsThreads; it < items; it += nparts * kLdsThreads) {
                     const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
                     const int xa = x0 + f;
-                    if (xa >= a.width) continue;
+                    if (xa >= a.x_end) continue;
                     const unsigned char *row = s_tile + f * tile_pitch;
                     uint32_t px[4];
 #pragma unroll
@@ -613,12 +613,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
     };
     int drain_x0 = -1;   // first frame of the group whose tile is still waiting for its write-out
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
-        const int x0 = g * group_frames;
+        const int x0 = a.frame0 + g * group_frames;
         for (int r = 0; r < rounds; r++) {
             const int fr = r * FPB + fs;            // frame within the group
             const int xr = x0 + fr;
-            const bool live = xr < a.width;
-            const int x = live ? xr : a.width - 1;  // surplus slots recompute the last frame and discard it
+            const bool live = xr < a.x_end;
+            const int x = live ? xr : a.x_end - 1;  // surplus slots recompute the last frame and discard it
             const int64_t start = frame_start(a.stride, x);
 
             double re[16], im[16];
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             constexpr bool TW0_LATE = PFB != 8;
             if constexpr (!STAGED && !TW0_LATE) load_pass_tw(tw0, tl, s_tw, stage_tw);
             // the frame this slot processes next
-            const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? (g + per_xcd) * group_frames + fs : -1);
+            const int xn = (r + 1 < rounds) ? xr + FPB : (g + per_xcd < g_end ? a.frame0 + (g + per_xcd) * group_frames + fs : -1);
             if constexpr (PF) {
                 if constexpr (PFB == 1) {
                     if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
             } else {
             // Touch the cache lines of the frame this slot processes next, so that its loads hit L2 instead of HBM.
             asm volatile("" ::"v"(pf_word));   // the previous touch has long landed; this only keeps the load alive
-            if (a.in_bounds && xn >= 0 && xn < a.width) {
+            if (a.in_bounds && xn >= 0 && xn < a.x_end) {
                 const int lines = (N * a.sample_width + 127) >> 7;
                 const int64_t nb = (int64_t)frame_start(a.stride, xn) * a.sample_width;
                 for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
@@ -963,9 +963,9 @@ inline int launch_lds(const FrameArgs &a, int format, const double2 *stage_tw, i
     static const int cu_env = getenv("SP_CU_LIMIT") ? atoi(getenv("SP_CU_LIMIT")) : 0;   // measurements only (tools/overhead.py)
     if (cu_env > 0 && cu_env < cu_count) cu_count = cu_env;
 #endif
-    while (want > 4 && (a.width + want - 1) / want < 2 * cu_count) want >>= 1;
+    while (want > 4 && (a.x_end - a.frame0 + want - 1) / want < 2 * cu_count) want >>= 1;
     const int gf = lds_group_frames(n, want);
-    const int groups = (a.width + gf - 1) / gf;
+    const int groups = (a.x_end - a.frame0 + gf - 1) / gf;
     const LdsLayout lay = lds_layout(n, a.lut_len, gf);
     int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;

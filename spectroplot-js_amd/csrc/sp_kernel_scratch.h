@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameA
     __syncthreads();
 
     double blk_mn = spjs::inf(), blk_mx = 0.0;   // thread 0: over this workgroup's frames
-    for (int x = a.frame0 + blockIdx.x; x < a.width; x += gridDim.x) {
+    for (int x = a.frame0 + blockIdx.x; x < a.x_end; x += gridDim.x) {
         const int64_t start = frame_start(a.stride, x);
 
         // decode + taper, stored in bit-reversed order (fft_nayuki.js:57-69)            worker.js:70-75

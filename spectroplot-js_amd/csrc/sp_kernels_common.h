@@ -16,7 +16,7 @@ struct FrameArgs {
     int32_t n, levels, width;
     int32_t channel_mode, waterfall, lut_len;
     int32_t in_bounds;           // every frame lies inside the buffer: unchecked loads are safe
-    int32_t frame0;              // first frame of this launch (always 0 today)
+    int32_t frame0, x_end;       // frames [frame0, x_end) of the image are rendered by this launch (sp_render renders in chunks)
     int32_t sample_width;        // bytes per complex sample
     const double *window;        // [n]
     const double *cos_t;         // [n/2]

@@ -10,6 +10,7 @@
 //   parseFormat(name)                              -> {id, sampleWidth}
 //   window(name, n)                                -> {window: Float64Array, weight}
 //   sliceBounds(nbytes, sampleWidth, index, count) -> [begin, end]
+//   poolStats()                                    -> {fresh, recycled, recycledPinned, freeBytes} of the reply-image pool
 //   cmap(name)                                     -> Uint8Array of r,g,b triples (the reference's map under its lookup rules) or null
 //   cmapKeys()                                     -> the reference's colour-map keys in its table order
 //   allocBuffer(nbytes)                            -> ArrayBuffer in page-locked host memory (sp_host_alloc): a request whose `buffer`
@@ -99,23 +100,36 @@ void ctx_release(Ctx *x)
 // of the same size.  Fresh memory is the slow part of a reply (the kernel zero-fills every page the copy from the device touches
 // for the first time); a recycled block takes the copy at the rate of the host link.  V8 is told the size of every block it
 // holds (napi_adjust_external_memory), so dropped replies are collected under memory pressure like any large ArrayBuffer.
+// A block that comes round a second time is page-locked (on the worker thread, once): copies into it then run asynchronously at
+// the rate of the host link, which is what lets sp_render overlap the image's way back with the samples' way in.
 struct HostPool {
-    struct Block { void *p; size_t size; };
+    struct Block { void *p; size_t size; bool pinned; };
     std::mutex m;
     std::vector<Block> free_blocks;
     size_t free_bytes = 0;
+    size_t n_fresh = 0, n_recycled = 0, n_recycled_pinned = 0;   // poolStats()
     static constexpr size_t kKeepBytes = (size_t)3 << 30;
-    void *take(size_t size)
+    void *take(size_t size, bool *pinned)
     {
+        *pinned = false;
         {
-            std::lock_guard<std::mutex> g(m);
+            std::unique_lock<std::mutex> g(m);
             for (size_t i = 0; i < free_blocks.size(); i++)
                 if (free_blocks[i].size == size) {
                     void *p = free_blocks[i].p;
+                    *pinned = free_blocks[i].pinned;
+                    n_recycled++;
+                    if (*pinned) n_recycled_pinned++;
                     free_bytes -= size;
                     free_blocks.erase(free_blocks.begin() + (long)i);
+                    g.unlock();
+                    if (!*pinned && size >= ((size_t)1 << 20)) *pinned = sp_host_register(p, size) == SP_OK;
                     return p;
                 }
+        }
+        {
+            std::lock_guard<std::mutex> g(m);
+            n_fresh++;
         }
         // large blocks on 2 MiB boundaries with transparent huge pages requested: the first touch of a fresh block then costs one
         // fault per 2 MiB instead of one per 4 KiB
@@ -127,26 +141,27 @@ struct HostPool {
 #endif
         return p;
     }
-    void give(void *p, size_t size)
+    void give(void *p, size_t size, bool pinned)
     {
         std::lock_guard<std::mutex> g(m);
         if (free_bytes + size > kKeepBytes) {
+            if (pinned) sp_host_unregister(p);
             free(p);
             return;
         }
-        free_blocks.push_back({p, size});
+        free_blocks.push_back({p, size, pinned});
         free_bytes += size;
     }
 };
 HostPool g_pool;
 
-struct PoolTag { size_t size; };
+struct PoolTag { size_t size; bool pinned; };
 void pool_free_cb(napi_env env, void *data, void *hint)
 {
     PoolTag *t = (PoolTag *)hint;
     int64_t total = 0;
     napi_adjust_external_memory(env, -(int64_t)t->size, &total);
-    g_pool.give(data, t->size);
+    g_pool.give(data, t->size, t->pinned);
     delete t;
 }
 
@@ -162,6 +177,7 @@ struct Job {
     // outputs: the image in a recycled block, the gauges malloc'd; handed to JS as external ArrayBuffers
     uint8_t *rgba = nullptr, *gmin = nullptr, *gmax = nullptr, *gamp = nullptr;
     size_t rgba_size = 0;
+    bool rgba_pinned = false;
     std::vector<uint64_t> c_hist, cb_hist;
     double minmax[2] = {0.0, -200.0};
     int status = SP_OK;
@@ -236,7 +252,7 @@ void run_job(Job *j)
 {
     const size_t W = j->width > 0 ? (size_t)j->width : 0, n = j->req.n > 0 ? (size_t)j->req.n : 0;
     j->rgba_size = 4 * W * n + 1;
-    j->rgba = (uint8_t *)g_pool.take(j->rgba_size);
+    j->rgba = (uint8_t *)g_pool.take(j->rgba_size, &j->rgba_pinned);
     j->gmin = (uint8_t *)calloc(W + 1, 1);
     j->gmax = (uint8_t *)calloc(W + 1, 1);
     j->gamp = (uint8_t *)calloc(W + 1, 1);
@@ -268,7 +284,7 @@ napi_value make_reply(napi_env env, Job *j)
     };
     {
         napi_value ab;
-        PoolTag *tag = new PoolTag{j->rgba_size};
+        PoolTag *tag = new PoolTag{j->rgba_size, j->rgba_pinned};
         if (napi_create_external_arraybuffer(env, j->rgba, 4 * W * n, pool_free_cb, tag, &ab) == napi_ok) {
             int64_t total = 0;
             napi_adjust_external_memory(env, (int64_t)j->rgba_size, &total);
@@ -298,7 +314,7 @@ napi_value make_reply(napi_env env, Job *j)
 
 void free_job(napi_env env, Job *j)
 {
-    if (j->rgba) g_pool.give(j->rgba, j->rgba_size);
+    if (j->rgba) g_pool.give(j->rgba, j->rgba_size, j->rgba_pinned);
     free(j->gmin); free(j->gmax); free(j->gamp);
     if (j->ctx_ref) napi_delete_reference(env, j->ctx_ref);
     if (j->cb_ref) napi_delete_reference(env, j->cb_ref);
@@ -506,6 +522,18 @@ napi_value AllocBuffer(napi_env env, napi_callback_info info)
     return ab;
 }
 
+napi_value PoolStats(napi_env env, napi_callback_info)
+{
+    napi_value out, v;
+    napi_create_object(env, &out);
+    std::lock_guard<std::mutex> g(g_pool.m);
+    napi_create_double(env, (double)g_pool.n_fresh, &v); napi_set_named_property(env, out, "fresh", v);
+    napi_create_double(env, (double)g_pool.n_recycled, &v); napi_set_named_property(env, out, "recycled", v);
+    napi_create_double(env, (double)g_pool.n_recycled_pinned, &v); napi_set_named_property(env, out, "recycledPinned", v);
+    napi_create_double(env, (double)g_pool.free_bytes, &v); napi_set_named_property(env, out, "freeBytes", v);
+    return out;
+}
+
 napi_value Cmap(napi_env env, napi_callback_info info)
 {
     size_t argc = 1;
@@ -573,6 +601,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"createContext", nullptr, CreateContext, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"destroyContext", nullptr, DestroyContext, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"allocBuffer", nullptr, AllocBuffer, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"poolStats", nullptr, PoolStats, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"cmap", nullptr, Cmap, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"cmapKeys", nullptr, CmapKeys, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -379,6 +379,23 @@ def test_pixels_straddling_every_index_edge(pkg, ctx):
     assert len(np.unique(want["rgba"].reshape(-1, 4)[:, 0])) > 250
 
 
+@pytest.mark.parametrize("fmt,lg,n,width,wf", [("CF32", 21, 1024, 2048, False), ("CF32", 21, 1024, 2000, True), ("CU8", 23, 512, 16384, False),
+                                                ("CS16", 22, 2048, 3001, False)],
+                         ids=["cf32_hop", "cf32_frac_wf", "cu8_8chunks", "cs16_overlap"])
+def test_large_host_requests_render_in_overlapped_chunks(pkg, ctx, fmt, lg, n, width, wf):
+    """sp_render walks a large request in chunks of frames (samples in, render, image band out on three streams).  Whole
+    reply against the oracle: chunk seams (frame groups, copied byte ranges, column / row bands) must not show."""
+    S = 1 << lg
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 321, "step": 7321, "gshift": 11, "amp": 0.5, "namp": 0.02}, S)
+    win, weight = pyoracle.window("hann", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+    for _ in range(2):                                   # twice: the second request reuses streams, events and staging buffers
+        got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+        _assert_same(got, want)
+
+
 def test_nonfinite_taper_is_exact(pkg, ctx):
     """A caller-supplied taper may hold infinities or NaN (options.windowF is any function).  Inf * 1 + Inf * 0 is NaN in the
     reference's first butterfly, so the kernels that skip the products of (1, 0) butterflies must not serve such a plan."""

@@ -1,24 +1,51 @@
-"""Host-buffer path (sp_render: what HipWorker calls): PCIe-inclusive time for a config-2-sized request, measured, for DESIGN.md section 5."""
-import sys, os, time, numpy as np
+"""Host-buffer path (sp_render: what HipWorker calls): PCIe-inclusive time of a config-2-sized request through the C ABI, for four
+kinds of host buffers: fresh pageable reply (what a naive caller does), reused pageable, and page-locked request / reply
+(sp_host_alloc).  DESIGN.md section 8."""
+import ctypes as C, sys, os, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package
 import siggen
 pkg = load_package()
+from spectroplot_js_amd import binding as B
 ctx = pkg.Context(0)
+L = ctx.lib.L
 n, fmt = 1024, "CF32"
 W = 16384; S = W * n
 data = siggen.generate(fmt, {"kind": "trinoise", "seed": 0x5EED0001, "step": 7321, "gshift": 11, "amp": 0.5, "namp": 0.02}, S)
 win, weight = pkg.window("blackmanHarris", n)
 i = np.arange(256)
 lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
-for _ in range(3):
-    ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W)
-ts = []
-for _ in range(10):
-    t0 = time.perf_counter()
-    ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W)
-    ts.append(time.perf_counter() - t0)
-t = float(np.median(ts))
-print("sp_render cfg2: %.2f ms per request (%d MiB in, %d MiB out): %.1f M frames/s, %.1f GB/s over PCIe both ways" %
-      (t * 1e3, data.nbytes >> 20, (4 * W * n) >> 20, W / t / 1e6, (data.nbytes + 4 * W * n) / t / 1e9))
+fid, _ = B.parse_format(fmt)
+req, keep = B._make_request(fid, n, win, 1.0 / weight, 6.0, 30.0, lut, False, False)
+L.sp_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+
+
+def pinned(nbytes):
+    p = C.c_void_p()
+    assert L.sp_host_alloc(nbytes, C.byref(p)) == 0
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+
+def run(inp, out_rgba, fresh_out, reps=10):
+    small = [np.zeros(W, np.uint8) for _ in range(3)] + [np.zeros(256, np.uint64), np.zeros(1000, np.uint64), np.zeros(2)]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    ts = []
+    for r in range(reps + 3):
+        if fresh_out:
+            out_rgba = np.empty(4 * W * n, np.uint8)
+        rep = B._Reply(p(out_rgba), p(small[0]), p(small[1]), p(small[2]), p(small[3]), p(small[4]), p(small[5]))
+        t0 = time.perf_counter()
+        assert L.sp_render(ctx.h, C.byref(req), p(inp), inp.size, W, C.byref(rep)) == 0
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts[3:])) * 1e3, int(small[3].sum())
+
+
+pin_in = pinned(data.size); pin_in[:] = data
+pin_out = pinned(4 * W * n)
+page_out = np.zeros(4 * W * n, np.uint8)
+for name, inp, out, fresh in (("pageable request, fresh pageable reply", data, None, True), ("pageable request, reused pageable reply", data, page_out, False),
+                              ("pageable request, page-locked reply", data, pin_out, False), ("page-locked request and reply", pin_in, pin_out, False)):
+    ms, total = run(inp, out, fresh)
+    assert total == W * n
+    print("sp_render cfg2, %-42s %6.2f ms per request = %5.1f GB/s over PCIe both ways" % (name + ":", ms, (data.nbytes + 4 * W * n) / ms / 1e6))
