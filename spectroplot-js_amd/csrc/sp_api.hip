@@ -648,10 +648,16 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
 
     int rc = ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
+    const int which = plan_kernel(plan);
     int finish_blocks = 3 * ((width + spk::kFinishThreads - 1) / spk::kFinishThreads);   // three roles per 256 frames
+    int finish_gauge_block0 = 0;
     {
         const int bins = plan->req.lut_len > SP_CB_HIST_SIZE ? plan->req.lut_len : SP_CB_HIST_SIZE;   // it also moves the histograms
         const int hb = (bins + spk::kFinishThreads - 1) / spk::kFinishThreads;
+        if (which == 3) {            // merged cells: the histogram workgroups serve no frames
+            finish_gauge_block0 = hb;
+            finish_blocks += hb;
+        }
         if (finish_blocks < hb) finish_blocks = hb;
         const int cb = (spk2::kMaxCells * spk2::kCellCopies + spk::kFinishThreads - 1) / spk::kFinishThreads;
         if (finish_blocks < cb) finish_blocks = cb;
@@ -723,7 +729,6 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     a.rgba_fast = out->rgba && ((uintptr_t)out->rgba & 15) == 0 && (width & 3) == 0 && width < (1 << 24)
                   && (double)width * (double)n * 4.0 <= 4294967296.0;
 
-    const int which = plan_kernel(plan);
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (which == 3) {
 #ifdef SP_STAMPS
@@ -791,6 +796,7 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         fa.cells = plan->th.cells;
         fa.cells_cap = spk2::kMaxCells;
         fa.cell_copies = spk2::kCellCopies;
+        fa.gauge_block0 = finish_gauge_block0;
         ctx->cell_toggle ^= 1;
     }
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);

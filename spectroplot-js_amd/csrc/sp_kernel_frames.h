@@ -81,7 +81,7 @@ __host__ __device__ inline int group_frames_for(int n, int want, int threads)
 }
 
 struct Layout {
-    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_win, total;
+    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_win, total;
 };
 
 __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds, bool win_lds = true)
@@ -97,6 +97,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
+    l.off_done = o;   o += 8;                                    // arrival counters of the two wave sets (SP_X_HALVES)
     o = (o + 7) & ~7;
     l.off_win = o;    o += (win_lds && lds_win_in_lds(n)) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
@@ -188,8 +189,10 @@ __device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_
         stamp_sum[k] += now_ - stamp_last;                            \
         stamp_last = now_;                                            \
     }
+#define SP_TAIL_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tail_stamp[k]) :: "memory");
 #else
 #define SP_STAMP(k)
+#define SP_TAIL_STAMP(k)
 #endif
 
 template <int LOG2N, bool CH, int PFB, int WAVES, bool EDGES_LDS>
@@ -205,8 +208,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifndef SP_X_STAGED
 #define SP_X_STAGED 0
 #endif
+#ifndef SP_X_HALVES
+#define SP_X_HALVES 1
+#endif
 #ifndef SP_X_LATEPF
 #define SP_X_LATEPF 0
+#endif
+#ifdef SP_STAMPS
+    unsigned long long stamp_entry, stamp_entry_rt;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry), "=s"(stamp_entry_rt) :: "memory");
 #endif
     constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED;  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
     // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     unsigned char *s_tile = smem + lay.off_tile;
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
     unsigned int *s_cells = (unsigned int *)(smem + lay.off_cells);      // word c counts the pixels with colour index + level == c
+    [[maybe_unused]] unsigned int *s_done = (unsigned int *)(smem + lay.off_done);
 
     const int tid = threadIdx.x;
     [[maybe_unused]] const int lane = tid & 63;
@@ -274,11 +285,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
         }
     };
-    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs);
-    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs);
+    // (SP_X_HALVES) the first / second waves of the SIMDs each take one half of a group's frames
+    const bool HALVES = SP_X_HALVES && WAVES == 8 && T == 64 && group_frames == 32;
+    const int fs0 = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + fs % (FPB / 2) : fs;     // the slot's frame in a group's first round
+    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
+    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
 
+    // two 4-wave workgroups per CU (80 KiB of LDS each): the taper does not fit and is re-read from L2 like in the DMA variant
+    constexpr bool WIN_GLOBAL = DMA || (WAVES == 4 && lds_win_in_lds(N));
+    constexpr bool WIN_LDS = lds_win_in_lds(N) && !WIN_GLOBAL;
+    double *s_win = (double *)(smem + lay.off_win);
     {
         // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
+        constexpr int WINK = WIN_LDS ? (N + kThreads - 1) / kThreads : 1;
+        double win_r[WINK];
+        if constexpr (WIN_LDS) {
+#pragma unroll
+            for (int k = 0; k < WINK; k++) {
+                const int i = tid + k * kThreads, e = i / T, t = i % T;
+                win_r[k] = i < N ? a.window[rev4(e) * T + (int)(__brev((unsigned)t) >> (32 - (LOG2N - 4)))] : 0.0;
+            }
+        }
         constexpr int NTW = lds_tw_entries(N);
         constexpr int TWK = (NTW + kThreads - 1) / kThreads;
         double2 tw_r[TWK > 0 ? TWK : 1];
@@ -312,21 +339,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
         }
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
+        if (tid < 2) s_done[tid] = 0;
+        if constexpr (WIN_LDS) {
+#pragma unroll
+            for (int k = 0; k < WINK; k++) {
+                const int i = tid + k * kThreads;
+                if (i < N) s_win[i] = win_r[k];
+            }
+        }
     }
 
-    // two 4-wave workgroups per CU (80 KiB of LDS each): the taper does not fit and is re-read from L2 like in the DMA variant
-    constexpr bool WIN_GLOBAL = DMA || (WAVES == 4 && lds_win_in_lds(N));
-    constexpr bool WIN_LDS = lds_win_in_lds(N) && !WIN_GLOBAL;
-    double *s_win = (double *)(smem + lay.off_win);
     const double *const wbase = s_win + tl;   // stored as the threads read it: entry e*T + tl = taper[rev4(e)*T + rev(tl)]
     double win_reg[(WIN_LDS || WIN_GLOBAL) ? 1 : 16];
     if constexpr (WIN_GLOBAL) {
         // nothing resident: 16 loads per frame from L2
     } else if constexpr (WIN_LDS) {
-        for (int i = tid; i < N; i += kThreads) {
-            const int e = i / T, t = i % T;
-            s_win[i] = a.window[rev4(e) * T + (int)(__brev((unsigned)t) >> (32 - (LOG2N - 4)))];
-        }
+        // loaded with the tables above
     } else {
         const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
 #pragma unroll
@@ -353,9 +381,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
 
     unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
-    const bool nt_rows = group_frames >= 32;
-    auto drain = [&](const int x0, const int part, const int nparts) {
-        if (part == 0 && tid < group_frames) {
+    // write-out of tile rows [f0, f0 + fcount) by the threads [t0, t0 + dthreads), slice `part` of `nparts`; slice 0 of a whole-group
+    // call also hands over the frames' extremes
+    auto drain_rows = [&](const int x0, const int part, const int nparts, const int f0, const int fcount, const int t0, const int dthreads,
+                          const bool extremes, const bool nt_rows) {
+        const int dt = tid - t0;
+        if (extremes && part == 0 && tid < group_frames) {
             if (x0 + tid < a.x_end) {
                 unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
 #pragma unroll
@@ -380,20 +411,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 // one of a thread's four dwords (bins tl + (4*e4 + j)*T, j = 0..3) of 4 consecutive frames: four 16-byte stores in four
                 // rows; the items of a row segment (8 frame quads) sit in lanes 4 apart, and a wave's dword reads are conflict-free
                 // (tile pitch = 1 dword mod 8).
-                const int quads = group_frames / 4;
+                const int quads = fcount / 4;
                 const int items = (N / 4) * quads;
-                for (int it0 = tid + part * 2 * kThreads; it0 < items; it0 += nparts * 2 * kThreads) {
+                for (int it0 = dt + part * 2 * dthreads; it0 < items; it0 += nparts * 2 * dthreads) {
                     uint32_t gb[2][4];
                     int i0v[2], xav[2];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const int it = it0 + u * kThreads;
+                        const int it = it0 + u * dthreads;
                         const int itc = it < items ? it : it0;
                         const int e4 = itc & 3, fq = (itc >> 2) % quads, tq = (itc >> 2) / quads;   // tq: thread of the frame
                         i0v[u] = tq + 4 * e4 * T;
-                        xav[u] = it < items ? x0 + fq * 4 : a.x_end;
+                        xav[u] = it < items ? x0 + f0 + fq * 4 : a.x_end;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (fq * 4 + k) * tile_pitch + tq * 16 + e4 * 4);
+                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (f0 + fq * 4 + k) * tile_pitch + tq * 16 + e4 * 4);
                     }
                     uint32_t px[2][4][4];
 #pragma unroll
@@ -420,6 +451,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                                 const unsigned off = (__umul24(y, (unsigned)a.width) + (unsigned)xa) * 4u;
 #ifdef SP_ABL_NOSTORE
                                 if (px[u][j][0] != 0x12345678u) continue;
+#endif
+#ifdef SP_ABL_HALFSTORE   // probe: do the stores of the other workgroups get cheaper when half of them store nothing?
+                                if (((blockIdx.x >> 3) & 1) && px[u][j][0] != 0x12345678u) continue;
 #endif
                                 // written once, never read by this kernel: non-temporal where a group's row segments are whole
                                 // 128-byte lines, so that the image does not displace the capture's lines in L2 (measured: 2.5 % of the
@@ -455,9 +489,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 }
             } else {
                 // waterfall: image is width rows x n columns; frame x is row width-1-x, bin i is column (i + n/2 - 1) mod n
-                const int items = group_frames * (N / 4);
-                for (int it = tid + part * kThreads; it < items; it += nparts * kThreads) {
-                    const int c4 = (it % (N / 4)) * 4, f = it / (N / 4);
+                const int items = fcount * (N / 4);
+                for (int it = dt + part * dthreads; it < items; it += nparts * dthreads) {
+                    const int c4 = (it % (N / 4)) * 4, f = f0 + it / (N / 4);
                     const int xa = x0 + f;
                     if (xa >= a.x_end) continue;
                     const unsigned char *row = s_tile + f * tile_pitch;
@@ -473,6 +507,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
         }
     };
+    // non-temporal stores where a group's row pieces are whole 128-byte lines (below)
+    auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, true, group_frames >= 32); };
     int drain_x0 = -1;
 #ifdef SP_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64(), stamp_slow = 0;
@@ -486,7 +522,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             if (r == 0 && (tid >> 8) == 1)
                 for (int q = 0; q < SP_X_STAGGER; q++) __builtin_amdgcn_s_sleep(32);
 #endif
-            const int fr = r * FPB + fs;
+#ifdef SP_X_ALTPRIO
+            // issue arbitration favours the older wave of a SIMD, which then waits for the younger one at the group's barrier: the two
+            // take turns at the higher priority, round by round
+            if (((r + (tid >> 8)) & 1) != 0) __builtin_amdgcn_s_setprio(SP_X_ALTPRIO);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
+            // HALVES: the first waves of the SIMDs (slots 0 .. FPB/2-1) own the group's first half of the frames, the second waves the
+            // other half, so that each set can write its half out by itself after the workgroup's last group
+            const int fr = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + r * (FPB / 2) + fs % (FPB / 2) : r * FPB + fs;
             const int xr = x0 + fr;
             if (fr >= group_frames) continue;   // a slot without a frame in the group's last round (its next frame is already requested)
             const bool live = xr < a.x_end;
@@ -513,8 +557,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
             }
             // the frame this slot processes next: the same slot one round on, or its frame in the workgroup's next group
-            const int xn = (r + 1 < rounds && fr + FPB < group_frames) ? xr + FPB
-                                                                         : (g + per_xcd < g_end ? a.frame0 + (g + per_xcd) * group_frames + fs : -1);
+            const int xn = (r + 1 < rounds && (HALVES || fr + FPB < group_frames)) ? xr + (HALVES ? FPB / 2 : FPB)
+                                                                         : (g + per_xcd < g_end ? a.frame0 + (g + per_xcd) * group_frames + fs0 : -1);
             if constexpr (DMA) {
                 // the samples are in the exchange buffer once the wave's LDS-DMA operations have landed
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -821,27 +865,48 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     }
 
 #ifdef SP_STAMPS
+    unsigned long long tail_stamp[4] = {0, 0, 0, 0};
     {
         const unsigned long long loop_end = clock64();
         if (lane == 0 && a.scratch) {
-            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 8;
+            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 16;
             for (int k = 0; k < 6; k++) dst[k] = stamp_sum[k];
             dst[6] = loop_end - stamp_begin;
             dst[7] = stamp_slow;
+            dst[8] = stamp_begin - stamp_entry;   // prologue
+            dst[15] = loop_end;
         }
     }
 #endif
     // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
+    if (HALVES && drain_x0 >= 0 && a.rgba) {
+        // The workgroup's last write-out overlaps nothing.  The first waves of the SIMDs reach it ~7 us before the second ones (config 2;
+        // issue arbitration favours the older wave, s_setprio does not change that - tools/stamps.py) and would wait at the barrier:
+        // each set of four waves meets by itself and writes its own half of the group, 64-byte pieces of the image rows, so half of the
+        // chip's last stores are under way while the second waves still compute.
+        const int half = tid >> 8;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&s_done[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u) __builtin_amdgcn_s_sleep(2);
+        // (non-temporal: left in L2, the 64-byte pieces are written back when the kernel ends, +1.2 us instead of -1.1 us; the first
+        // set also taking half of the second set's rows once those are ready: no further gain)
+        drain_rows(drain_x0, 0, 1, half * (group_frames / 2), group_frames / 2, half * (kThreads / 2), kThreads / 2, false, true);
+    }
     lds_barrier();
+    SP_TAIL_STAMP(0)
     for (int i = tid; i < a.cells; i += kThreads) {
         const unsigned int v = s_cells[i];
         // one copy per XCD (workgroups b and b + 8 share one): 32 adders per word instead of 256
         if (v) atomicAdd(&a.cell_acc[(size_t)xcd * a.cells_cap + i], (unsigned long long)v);
     }
+    SP_TAIL_STAMP(1)
     if (drain_x0 >= 0) {
-        drain(drain_x0, 0, 1);
+        if (HALVES && a.rgba) drain_rows(drain_x0, 0, 1, 0, 0, 0, kThreads, true, false);   // the extremes only
+        else drain(drain_x0, 0, 1);
+        SP_TAIL_STAMP(2)
         lds_barrier();
     }
+    SP_TAIL_STAMP(3)
     if (tid < group_frames) {
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
         if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
@@ -851,6 +916,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
         if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
         if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
     }
+#ifdef SP_STAMPS
+    {
+        unsigned long long t_end, rt_end;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end) :: "memory");
+        if (lane == 0 && a.scratch) {
+            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 16;
+            dst[9] = t_end - stamp_entry;          // whole wave, shader clock
+            dst[10] = rt_end - stamp_entry_rt;     // whole wave, constant 100 MHz clock
+            dst[11] = stamp_entry_rt;              // start time (spread of the launch over the workgroups)
+            const unsigned long long le = dst[15];
+            dst[12] = tail_stamp[0] - le;            // wait at the barrier after the loop
+            unsigned hw_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            dst[13] = hw_id;                         // wave slot [3:0], SIMD [5:4], CU [11:8], SE [15:13]
+            dst[14] = tail_stamp[2] - tail_stamp[1]; // last write-out issued
+            dst[15] = t_end - tail_stamp[2];         // barrier, extremes, outstanding stores and atomics
+        }
+    }
+#endif
 }
 
 // Waves per workgroup (one workgroup per CU): 8 = two per SIMD with the edge tables in LDS; 12 = three per SIMD (<= 168 VGPRs,

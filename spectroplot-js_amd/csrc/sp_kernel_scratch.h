@@ -155,6 +155,7 @@ struct FinishArgs {
     unsigned long long *cell_clear;
     const uint16_t *cell_g, *cell_l;
     int32_t cells, cells_cap, cell_copies;
+    int32_t gauge_block0;     // the first workgroup that serves frames: the ones before it only turn the cells into histograms
 };
 
 // store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
@@ -182,14 +183,16 @@ constexpr int kFinishThreads = 256;
 // d = dBfs - gain of one |X|^2 value, the reference's operation order                     worker.js:100,124-125
 __device__ inline double d_of_abs2(double abs2, double block_norm_db, double gain) { return (5 * spjs::log10(abs2) + block_norm_db + gain) - gain; }
 
-// Grid: 3 * ceil(width / kFinishThreads) workgroups (at least enough threads for the histograms).  The three software
-// log10 evaluations a frame needs are independent, so they run in different workgroups (role = blockIdx % 3) instead of as
-// one long dependent chain per thread.
+// Grid: gauge_block0 + 3 * ceil(width / kFinishThreads) workgroups (at least enough threads for the histograms).  The three
+// software log10 evaluations a frame needs are independent, so they run in different workgroups (role = block % 3) instead of
+// as one long dependent chain per thread; with merged cells the workgroups that build the histograms (loads, a scan) serve no
+// frames, so the kernel's two dependent chains run side by side.
 __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishArgs a)
 {
-    const int role = blockIdx.x % 3;
-    const int x = (blockIdx.x / 3) * kFinishThreads + threadIdx.x;
-    if (x < a.width) {
+    const int fb = (int)blockIdx.x - a.gauge_block0;
+    const int role = fb % 3;
+    const int x = (fb / 3) * kFinishThreads + threadIdx.x;
+    if (fb >= 0 && x < a.width) {
         // d is monotone in abs2, so the frame's extreme d values come from its extreme abs2 values
         if (role == 0) {
             if (a.gauge_mins) {

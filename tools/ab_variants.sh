@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp SP_EXPERIMENT_KNOBS=1
 for rep in 1 2; do
 for v in $1; do
   if [ "$v" = "-" ]; then unset SP_LIB_VARIANT; else export SP_LIB_VARIANT=$v; fi
+  if [ "$v" != "-" ] && [ ! -f $ROOT/spectroplot-js_amd/lib/variants/$v.so ]; then echo "variant $v: not built, skipped"; continue; fi
   rm -rf /tmp/ab_$v
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --steps 400 --warmup 100 --config $CFG --kernel $K $4 > /tmp/ab_$v.log 2>&1
   f=$(find /tmp/ab_$v -name "*kernel_stats.csv" | head -1)
