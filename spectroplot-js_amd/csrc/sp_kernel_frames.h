@@ -22,6 +22,14 @@
 
 #include "sp_kernel_lds.h"
 
+// experiment switches of the large-n layout (defaults = the shipped kernel)
+#ifndef SP_X_TWMAX_BIG
+#define SP_X_TWMAX_BIG 9
+#endif
+#ifndef SP_X_TILE_BIG
+#define SP_X_TILE_BIG 65536
+#endif
+
 namespace spk2 {
 
 using namespace spk;
@@ -67,13 +75,19 @@ __host__ __device__ inline bool frames_kernel_supports(int n, int waves)
     return T <= threads && threads % T == 0;
 }
 
+// n >= 4096: the twiddle tables of stages 1-9 only stay in LDS (stage 10 joins 11-13 in L2: two more loads per thread and frame),
+// which makes room for a 64 KiB tile: 16 / 8 frames per group instead of 8 / 4, i.e. 64 / 32-byte pieces of the image rows instead of
+// 32 / 16 and half as many group barriers (config 5 wrote 2.1 x its image with 16-byte pieces)
+__host__ __device__ inline constexpr int frames_tw_max_stage(int n) { return n >= 4096 ? SP_X_TWMAX_BIG : kLdsTwMaxStage; }
+__host__ __device__ inline constexpr int frames_tw_entries(int n) { return n < (1 << frames_tw_max_stage(n)) ? n : (1 << frames_tw_max_stage(n)); }
+
 // frames per output group (tile height): a multiple of the frames per round and of 4 (the write-out handles frame quads)
 __host__ __device__ inline int group_frames_for(int n, int want, int threads)
 {
     const int fpb = threads * 16 / n;
     int unit = fpb;
     while (unit % 4) unit *= 2;          // lcm(fpb, 4) for fpb in {1, 2, 3, 6, 12, ...}
-    int cap = 32768 / n;
+    int cap = (n >= 4096 ? SP_X_TILE_BIG : 32768) / n;
     if (cap > want) cap = want;
     int f = cap / unit * unit;
     if (f < unit) f = unit;
@@ -89,7 +103,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     Layout l;
     const int fpb = threads * 16 / n;
     int o = fpb * (n + n / 16) * 8;                              // exchange buffers
-    l.off_tw = o;     o += lds_tw_entries(n) * 16;
+    l.off_tw = o;     o += frames_tw_entries(n) * 16;
     l.off_gedge = o;  o += edges_lds ? lut_len * 8 : 0;
     l.off_cbedge = o; o += edges_lds ? (SP_CB_HIST_SIZE + 1) * 8 : 0;
     o = (o + 15) & ~15;
@@ -97,7 +111,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
-    l.off_done = o;   o += 8;                                    // arrival counters of the two wave sets (SP_X_HALVES)
+    l.off_done = o;   o += 32;                                   // arrival counters: the two wave sets (last write-out), the frames' waves
     o = (o + 7) & ~7;
     l.off_win = o;    o += (win_lds && lds_win_in_lds(n)) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
@@ -195,6 +209,45 @@ __device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_
 #define SP_TAIL_STAMP(k)
 #endif
 
+// The waves that share a frame (n = 2048: two, n = 4096: four) meet through an LDS counter instead of the workgroup barrier, which
+// held every frame of a round to the pace of the slowest wave and kept all waves in the same phase (all in the VALU, then all in the
+// LDS).  Every LDS operation a wave has issued is ahead of its increment in the LDS queue (a wave's LDS operations execute in
+// order), so "my writes are visible" and "my reads are done" both hold once the partners see the count.
+template <bool COUNTER, bool BLOCK_SYNC>
+struct FrameMeet {
+    unsigned addr;     // LDS byte address of the frame's counter (wave-uniform)
+    unsigned target;   // the count once every wave of the frame has arrived the next time
+    unsigned step;     // waves per frame
+    __device__ inline void operator()()
+    {
+        if constexpr (COUNTER) {
+            // one asm block (a C loop around an atomic splits the kernel's big basic blocks and costs the register allocator 60+
+            // spilled VGPRs): lane 0 adds one, then the wave polls the counter
+            target = (unsigned)__builtin_amdgcn_readfirstlane((int)(target + step));   // wave-uniform, kept in an SGPR
+            unsigned long long save;
+            unsigned a_v, got_v, got_s;
+            asm volatile("v_mov_b32 %[a_v], %[addr]\n\t"
+                         "v_mov_b32 %[got_v], 1\n\t"
+                         "s_mov_b64 %[save], exec\n\t"
+                         "s_mov_b64 exec, 1\n\t"
+                         "ds_add_u32 %[a_v], %[got_v]\n\t"
+                         "s_mov_b64 exec, %[save]\n"
+                         "L_sp_meet_%=:\n\t"
+                         "ds_read_b32 %[got_v], %[a_v]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_readfirstlane_b32 %[got_s], %[got_v]\n\t"
+                         "s_sub_i32 %[got_s], %[got_s], %[target]\n\t"
+                         "s_cmp_lt_i32 %[got_s], 0\n\t"
+                         "s_cbranch_scc1 L_sp_meet_%="
+                         : [save] "=&s"(save), [a_v] "=&v"(a_v), [got_v] "=&v"(got_v), [got_s] "=&s"(got_s)
+                         : [addr] "s"(addr), [target] "s"(target)
+                         : "memory", "scc");
+        } else {
+            spk::frame_sync<BLOCK_SYNC>();
+        }
+    }
+};
+
 template <int LOG2N, bool CH, int PFB, int WAVES, bool EDGES_LDS>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                        const int group_frames, const int groups)
@@ -204,9 +257,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     constexpr int T = N / 16;                       // threads per frame
     constexpr int FPB = kThreads / T;               // frames per round
     constexpr bool BLOCK_SYNC = T > 64;
+    constexpr int TWMAX = frames_tw_max_stage(N);
     constexpr int NPASS = (LOG2N + 3) / 4;
 #ifndef SP_X_STAGED
 #define SP_X_STAGED 0
+#endif
+#ifndef SP_X_COUNTER_SYNC
+#define SP_X_COUNTER_SYNC 1
 #endif
 #ifndef SP_X_HALVES
 #define SP_X_HALVES 1
@@ -245,6 +302,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const int fs = tid / T;                         // frame slot within a round
     const int tl = tid % T;                         // thread within the frame
     double *xbuf = s_xch + fs * (N + N / 16);
+    constexpr bool COUNTER_SYNC = SP_X_COUNTER_SYNC && BLOCK_SYNC && T < kThreads;   // a frame's waves are not the whole workgroup
+    FrameMeet<COUNTER_SYNC, BLOCK_SYNC> meet{
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) unsigned int *)(s_done + 2 + fs)),
+        0u, (unsigned)(T / 64)};
     const int tile_pitch = N + kTilePad;
     const int cmax = a.lut_len - 1;
 
@@ -306,7 +367,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 win_r[k] = i < N ? a.window[rev4(e) * T + (int)(__brev((unsigned)t) >> (32 - (LOG2N - 4)))] : 0.0;
             }
         }
-        constexpr int NTW = lds_tw_entries(N);
+        constexpr int NTW = frames_tw_entries(N);
         constexpr int TWK = (NTW + kThreads - 1) / kThreads;
         double2 tw_r[TWK > 0 ? TWK : 1];
 #pragma unroll
@@ -339,7 +400,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
         }
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
-        if (tid < 2) s_done[tid] = 0;
+        if (tid < 8) s_done[tid] = 0;
         if constexpr (WIN_LDS) {
 #pragma unroll
             for (int k = 0; k < WINK; k++) {
@@ -644,24 +705,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
-                PassTw<WS1, 5, STAGED ? 4 : E1> tw1;
+                PassTw<WS1, 5, STAGED ? 4 : E1, TWMAX> tw1;
                 if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
-                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
-                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1, meet);
+                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1, meet);
                 exchange_wait(re, im);
                 if constexpr (DMA) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the buffer has returned
                     if (xn >= 0) dma_request(xn);                       // in flight until the next frame starts
                 }
                 SP_STAMP(1)   // (first write-out slice,) first pass, first exchange
-                if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
+                if constexpr (STAGED) fft_pass_staged<WS1, 5, E1, TWMAX>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
                 if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
-                    PassTw<WS2, 9, STAGED ? 8 : E2> tw2;
+                    PassTw<WS2, 9, STAGED ? 8 : E2, TWMAX> tw2;
                     if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
 #ifndef SP_X_LDS_E2
                     if constexpr (LOG2N == 9 || LOG2N == 10) {
@@ -672,21 +733,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                     } else
 #endif
                     {
-                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
-                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2, meet);
+                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2, meet);
                 exchange_wait(re, im);
                     }
                     SP_STAMP(2)   // second pass, second exchange
-                    if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
+                    if constexpr (STAGED) fft_pass_staged<WS2, 9, E2, TWMAX>(re, im, tl, s_tw, tw);
                     else fft_pass<WS2, 9, E2>(re, im, tw2);
                     SP_STAMP(3)   // third pass
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
-                        PassTw<WS3, 13, LOG2N> tw3;
+                        PassTw<WS3, 13, LOG2N, TWMAX> tw3;
                         load_pass_tw(tw3, tl, s_tw, tw);
-                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
-                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
+                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3, meet);
+                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3, meet);
                 exchange_wait(re, im);
                         fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
@@ -696,10 +757,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 
             if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS (as k_lds_r16)
                 double pp[16];
-                frame_sync<BLOCK_SYNC>();
+                meet();
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
-                frame_sync<BLOCK_SYNC>();
+                meet();
 #pragma unroll
                 for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
 #pragma unroll
@@ -715,10 +776,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         re[e] = 0.5 * (-pp[e] + orr);
                     }
                 }
-                frame_sync<BLOCK_SYNC>();
+                meet();
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = im[e];
-                frame_sync<BLOCK_SYNC>();
+                meet();
 #pragma unroll
                 for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
 #pragma unroll

@@ -137,7 +137,8 @@ __device__ inline int pad_idx(int p) { return p + (p >> 4); }
 __device__ inline constexpr int win_off(int e, int ws) { return (e << ws) + ((e << ws) >> 4); }
 
 // Twiddles of one register pass: stages S0..S1 inside window [WS, WS+4); stage s needs 2^(s-1-WS) of them per thread.
-template <int WS, int S0, int S1>
+// (MAXS: the last stage whose table is in LDS; k_frames keeps fewer stages there for n >= 4096)
+template <int WS, int S0, int S1, int MAXS = kLdsTwMaxStage>
 struct PassTw {
     static constexpr int count = (1 << (S1 - WS)) - (1 << (S0 - 1 - WS));
     double2 w[count > 0 ? count : 1];
@@ -145,8 +146,8 @@ struct PassTw {
 
 // tw_lds: LDS copy of stage_tw[0 .. min(n, 1024)), tw_glb: the full table in HBM/L2.  Issued as one batch well before the
 // pass (ahead of the re-distribution that precedes it), so no butterfly waits on an LDS round trip.
-template <int WS, int S0, int S1>
-__device__ inline void load_pass_tw(PassTw<WS, S0, S1> &t, int tl, const double2 *__restrict__ tw_lds, const double2 *__restrict__ tw_glb)
+template <int WS, int S0, int S1, int MAXS>
+__device__ inline void load_pass_tw(PassTw<WS, S0, S1, MAXS> &t, int tl, const double2 *__restrict__ tw_lds, const double2 *__restrict__ tw_glb)
 {
     const int tl_low = tl & ((1 << WS) - 1);
     int k = 0;
@@ -158,7 +159,7 @@ __device__ inline void load_pass_tw(PassTw<WS, S0, S1> &t, int tl, const double2
         for (int j = 0; j < (1 << u); j++) {
             // twiddle index within the stage = position bits below bit s-1     fft_nayuki.js:76-78 (k = j * tablestep)
             const int m = tl_low | (j << WS);
-            t.w[k++] = s <= kLdsTwMaxStage ? tw_lds[half + m] : tw_glb[half + m];
+            t.w[k++] = s <= MAXS ? tw_lds[half + m] : tw_glb[half + m];
         }
     }
 }
@@ -167,8 +168,8 @@ __device__ inline void load_pass_tw(PassTw<WS, S0, S1> &t, int tl, const double2
 // TRIV: the butterflies of the first pass whose twiddle is entry 0 of its stage, (cos 0, sin 0) = (1, 0) exactly, skip the
 // four products: x*1 + y*0 = x bit for bit when x and y are finite (only the sign of a zero can differ, and no output depends
 // on it); with an infinite or NaN y the product y*0 is NaN, so the caller enables TRIV only for frames without such samples.
-template <int WS, int S0, int S1, bool TRIV = false>
-__device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw<WS, S0, S1> &t)
+template <int WS, int S0, int S1, bool TRIV = false, int MAXS>
+__device__ inline void fft_pass(double (&re)[16], double (&im)[16], const PassTw<WS, S0, S1, MAXS> &t)
 {
     int base = 0;
 #pragma unroll
@@ -219,18 +220,25 @@ __device__ inline void frame_sync()
     }
 }
 
+// How the threads of one frame meet around a re-distribution: frame_sync<BLOCK_SYNC>() as a function object (the default), or
+// a kernel's own (k_frames: the waves of a frame meet through an LDS counter).
+template <bool BLOCK_SYNC>
+struct FrameSyncDefault {
+    __device__ inline void operator()() const { frame_sync<BLOCK_SYNC>(); }
+};
+
 // Re-distribute the 16 values of every thread from window WS_FROM to window WS_TO through the frame's LDS buffer.
 // from / to point at this thread's element 0 under the respective window.
-template <int WS_FROM, int WS_TO, bool BLOCK_SYNC>
-__device__ inline void exchange(double (&v)[16], double *from, const double *to)   // from / to alias: no __restrict__
+template <int WS_FROM, int WS_TO, bool BLOCK_SYNC, class SYNC = FrameSyncDefault<BLOCK_SYNC>>
+__device__ inline void exchange(double (&v)[16], double *from, const double *to, SYNC &&sync = SYNC())   // from / to alias: no __restrict__
 {
 #ifdef SP_ABL_NOEXCH
     return;
 #endif
-    frame_sync<BLOCK_SYNC>();   // previous readers are done with the buffer
+    sync();   // previous readers are done with the buffer
 #pragma unroll
     for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
-    frame_sync<BLOCK_SYNC>();
+    sync();
 #if SP_ASM_READS
     // one ds_read_b64 per value: the compiler pairs them into ds_read2_b64, which the LDS serves at half the rate per byte
     const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)to;
@@ -385,16 +393,16 @@ __device__ inline bool decode_frame(const uint32_t (&lo)[16], const uint32_t (&h
 
 
 // A register pass whose twiddles are read stage by stage instead of as one batch ahead of the re-distribution.
-template <int WS, int S0, int S1>
+template <int WS, int S0, int S1, int MAXS = kLdsTwMaxStage>
 __device__ inline void fft_pass_staged(double (&re)[16], double (&im)[16], int tl, const double2 *__restrict__ tw_lds,
                                        const double2 *__restrict__ tw_glb)
 {
     if constexpr (S0 <= S1) {
-        PassTw<WS, S0, S0> t;
+        PassTw<WS, S0, S0, MAXS> t;
         load_pass_tw(t, tl, tw_lds, tw_glb);
         fft_pass<WS, S0, S0>(re, im, t);
         asm volatile("" ::: "memory");   // keep the next stage's reads behind this stage: at most 8 twiddles are live
-        fft_pass_staged<WS, S0 + 1, S1>(re, im, tl, tw_lds, tw_glb);
+        fft_pass_staged<WS, S0 + 1, S1, MAXS>(re, im, tl, tw_lds, tw_glb);
     }
 }
 
