@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
+    ap.add_argument("--merge-every", type=int, default=16,
+                    help="N > 1: the side-output records of this many renders travel in ONE all-gather (1 = one collective per render)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "lds", "frames"], help="A/B runs: force a device kernel")
     args = ap.parse_args()
 
@@ -177,43 +179,61 @@ def main():
     rgba_ptr = 0 if args.no_rgba else rgba.data_ptr()
     gauges = torch.empty(3 * W, dtype=torch.uint8, device=dev)
     # side outputs of one slice as one record [c_hist | cB_hist | dBfs_min, dBfs_max as f64 bits]: the library writes straight
-    # into it.  Two records in rotation: the all-gather of step k (RCCL's stream) overlaps the frame loop of step k+1.
+    # into it.  The records of M = --merge-every renders form one batch; two batches in rotation: the all-gather of a batch (RCCL's
+    # stream) overlaps the frame loops of the next one.  (The frame-loop kernel fills every CU - all of its VGPRs and 145 KiB of its LDS -
+    # so a collective's kernel waits for a CU and then holds up workgroups of the following launch: one collective per 80 us render
+    # would put that on every step; M renders per collective leave the exchange itself as it is and divide the interference by M.)
     L = len(lut)
     P = L + 1000 + 2
-    records = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(2)]
-    gathered = [torch.zeros(world * P, dtype=torch.int64, device=dev) for _ in range(2)] if world > 1 else None
+    M = max(1, args.merge_every) if world > 1 else 1
+    records = [torch.zeros(M * P, dtype=torch.int64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(world * M * P, dtype=torch.int64, device=dev) for _ in range(2)] if world > 1 else None
     merged_buf = torch.zeros(P, dtype=torch.int64, device=dev)
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "last": None}
 
-    def run_slice(rec):
-        p = rec.data_ptr()
+    def run_slice(rec, j=0):
+        p = rec.data_ptr() + 8 * P * j
         plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      p, p + 8 * L, p + 8 * (L + 1000))
 
-    def merge(slot):
-        # the caller's merge of the slices' side outputs (lib/spectroplot.js:1229-1238), on device
+    def merge(slot, count):
+        # the caller's merge of the slices' side outputs (lib/spectroplot.js:1229-1238), on device: render by render, every
+        # rank's record of that render side by side
+        by_render = gathered[slot].view(world, M, P).transpose(0, 1).contiguous() if M > 1 else gathered[slot]
         p = merged_buf.data_ptr()
-        ctx.merge_replies(gathered[slot].data_ptr(), world, L, p, p + 8 * L, p + 8 * (L + 1000))
+        for j in range(count):
+            ctx.merge_replies(by_render.data_ptr() + 8 * world * P * j, world, L, p, p + 8 * L, p + 8 * (L + 1000))
+
+    def ship(slot, count):
+        # every rank gathers all ranks' records of the batch (10 KB per render and rank); queued behind the batch's kernels, it
+        # runs while the next batch computes.  The previous batch's gather has long finished: merge it.
+        work = dist.all_gather_into_tensor(gathered[slot], records[slot], async_op=True)
+        if state["pending"] is not None:
+            pw, pslot, pcount = state["pending"]
+            pw.wait()
+            merge(pslot, pcount)
+        state["pending"] = (work, slot, count)
 
     def step():
-        slot = state["k"] & 1
+        k = state["k"]
         state["k"] += 1
-        run_slice(records[slot])
-        if dist is not None:
-            # ONE collective per render: every rank gathers all ranks' records (10 KB each); it is queued behind this
-            # step's kernels and runs while the next step computes.  The previous step's gather has long finished: merge it.
-            work = dist.all_gather_into_tensor(gathered[slot], records[slot], async_op=True)
-            if state["pending"] is not None:
-                pw, pslot = state["pending"]
-                pw.wait()
-                merge(pslot)
-            state["pending"] = (work, slot)
+        slot, j = (k // M) & 1, k % M
+        run_slice(records[slot], j)
+        state["last"] = (slot, j)
+        if dist is not None and j == M - 1:
+            ship(slot, M)
 
     def finish_pending():
+        if dist is None:
+            return
+        k = state["k"]
+        if k % M:                                             # a partial batch at the end of a run
+            ship((k // M) & 1, k % M)
+            state["k"] = (k // M + 1) * M
         if state["pending"] is not None:
-            pw, pslot = state["pending"]
+            pw, pslot, pcount = state["pending"]
             pw.wait()
-            merge(pslot)
+            merge(pslot, pcount)
             state["pending"] = None
 
     def sync():
@@ -239,7 +259,7 @@ def main():
     finish_pending()                                          # the last render's merge belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
-    final = merged_buf if dist is not None else records[(state["k"] - 1) & 1]
+    final = merged_buf if dist is not None else records[state["last"][0]][P * state["last"][1]:]
     hsum = int(final[:L].sum().item())                        # all slices after the merge
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -303,6 +323,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
                          "frac_of_copy_ceiling_6290": achieved / 6290.0},
             "checks": {"c_hist_sum": hsum, "expected": world * W * n},
+            "renders_per_collective": M if world > 1 else None,
         }
         if gather_ms is not None:
             out["rgba_gather_ms"] = gather_ms
