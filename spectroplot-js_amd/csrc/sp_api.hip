@@ -661,6 +661,7 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         if (finish_blocks < hb) finish_blocks = hb;
         const int cb = (spk2::kMaxCells * spk2::kCellCopies + spk::kFinishThreads - 1) / spk::kFinishThreads;
         if (finish_blocks < cb) finish_blocks = cb;
+        finish_blocks += 1;          // the dBfs range: a workgroup of its own, behind neither the histograms nor a gauge
     }
     // [16,32) bit patterns of the extreme |X|^2 of a launch, [64, ...) colour and centi-bel histogram accumulators
     // ... and two merged-cell buffers for k_frames (one counts while the finish kernel of the previous launch reads the other)

@@ -228,13 +228,22 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
         if (owner) {
             // the XCD copies of a cell are summed with coalesced loads (thread t takes cells t, t + 256, ...), then every thread picks
             // up its 8 consecutive cells from LDS
-            for (int c = threadIdx.x; c < kFinishThreads * kPer; c += kFinishThreads) {
+            // (every load of the thread is issued before the first sum: one memory latency instead of one per 256 cells)
+            constexpr int kCopies = 8;
+            unsigned long long part[kPer][kCopies];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int c = threadIdx.x + k * kFinishThreads;
+#pragma unroll
+                for (int x = 0; x < kCopies; x++)
+                    part[k][x] = (c < a.cells && x < a.cell_copies) ? a.cell_acc[(size_t)x * a.cells_cap + c] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
                 unsigned long long sum = 0ull;
-                if (c < a.cells) {
-#pragma unroll 8
-                    for (int x = 0; x < a.cell_copies; x++) sum += a.cell_acc[(size_t)x * a.cells_cap + c];
-                }
-                s_pre[c] = sum;
+#pragma unroll
+                for (int x = 0; x < kCopies; x++) sum += part[k][x];
+                s_pre[threadIdx.x + k * kFinishThreads] = sum;
             }
             __syncthreads();
             unsigned long long v[kPer], run = 0;
@@ -243,16 +252,20 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
                 v[k] = s_pre[threadIdx.x * kPer + k];
                 run += v[k];
             }
-            __syncthreads();
-            s_part[threadIdx.x] = run;
-            __syncthreads();
-            for (int d = 1; d < kFinishThreads; d <<= 1) {                // inclusive scan of the partial sums
-                const unsigned long long add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0ull;
-                __syncthreads();
-                s_part[threadIdx.x] += add;
-                __syncthreads();
+            // inclusive scan of the 256 partial sums: inside each wave with shuffles, the four wave totals through LDS
+            unsigned long long incl = run;
+            const int ln = threadIdx.x & 63;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long up = __shfl_up(incl, d, 64);
+                if (ln >= d) incl += up;
             }
-            unsigned long long base = s_part[threadIdx.x] - run;          // sum of the cells below this thread's first
+            __syncthreads();                                              // every thread has read its cells from s_pre
+            if (ln == 63) s_part[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            unsigned long long below = 0ull;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) below += s_part[w];
+            unsigned long long base = below + incl - run;                 // sum of the cells below this thread's first
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
                 s_pre[threadIdx.x * kPer + k] = base;                     // s_pre[c] = sum of cells [0, c)
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
     }
     // global dBfs range (worker.js:35-36,124-125): min over frames of min(0, d(frame_min)) = min(0, d(min over frames)),
     // by the same monotonicity; the frame-loop kernels left the extreme |X|^2 of the whole launch in mm_acc
-    if (blockIdx.x == 0 && threadIdx.x < 2) {
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 2) {   // the last workgroup serves no frames and no histogram (sp_api.hip)
         const double v = __longlong_as_double((long long)a.mm_acc[threadIdx.x]);
         const double d = d_of_abs2(v, a.block_norm_db, a.gain);
         if (threadIdx.x == 0) {
