@@ -274,6 +274,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifdef SP_STAMPS
     unsigned long long stamp_entry, stamp_entry_rt;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry), "=s"(stamp_entry_rt) :: "memory");
+    unsigned long long pro_stamp[3] = {0, 0, 0};
+#define SP_PRO_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_stamp[k]) :: "memory");
+#else
+#define SP_PRO_STAMP(k)
 #endif
     constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED;  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
     // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
@@ -356,6 +360,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     constexpr bool WIN_GLOBAL = DMA || (WAVES == 4 && lds_win_in_lds(N));
     constexpr bool WIN_LDS = lds_win_in_lds(N) && !WIN_GLOBAL;
     double *s_win = (double *)(smem + lay.off_win);
+    SP_PRO_STAMP(0)   // kernel arguments read, the first frame's samples requested
+    constexpr int MMS = mm_slots(N);
     {
         // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
         constexpr int WINK = WIN_LDS ? (N + kThreads - 1) / kThreads : 1;
@@ -385,6 +391,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
             }
         }
+        // what needs no table is set up while the loads are in flight (a table load takes ~2.3 us at the start of a launch)
+        for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
+        if (tid < 8) s_done[tid] = 0;
+        for (int i = tid; i < group_frames * MMS; i += kThreads) {
+            s_mm[2 * i] = 0x7ff0000000000000ull;
+            s_mm[2 * i + 1] = 0ull;
+        }
 #pragma unroll
         for (int k = 0; k < TWK; k++) {
             const int i = tid + k * kThreads;
@@ -399,8 +412,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 if (i <= SP_CB_HIST_SIZE) ((double *)(smem + lay.off_cbedge))[i] = cb_r[k];
             }
         }
-        for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
-        if (tid < 8) s_done[tid] = 0;
+        SP_PRO_STAMP(1)   // the tables have arrived (their LDS stores are issued)
         if constexpr (WIN_LDS) {
 #pragma unroll
             for (int k = 0; k < WINK; k++) {
@@ -424,11 +436,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifdef SP_X_SETPRIO
     if ((tid >> 8) == 1) __builtin_amdgcn_s_setprio(SP_X_SETPRIO);   // the second wave of every SIMD
 #endif
-    constexpr int MMS = mm_slots(N);
-    for (int i = tid; i < group_frames * MMS; i += kThreads) {
-        s_mm[2 * i] = 0x7ff0000000000000ull;
-        s_mm[2 * i + 1] = 0ull;
-    }
     lds_barrier();
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
@@ -930,11 +937,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     {
         const unsigned long long loop_end = clock64();
         if (lane == 0 && a.scratch) {
-            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 16;
+            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 20;
             for (int k = 0; k < 6; k++) dst[k] = stamp_sum[k];
             dst[6] = loop_end - stamp_begin;
             dst[7] = stamp_slow;
             dst[8] = stamp_begin - stamp_entry;   // prologue
+            dst[16] = pro_stamp[0] - stamp_entry;
+            dst[17] = pro_stamp[1] - pro_stamp[0];
+            dst[18] = stamp_begin - pro_stamp[1];
             dst[15] = loop_end;
         }
     }
@@ -982,7 +992,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
         unsigned long long t_end, rt_end;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end) :: "memory");
         if (lane == 0 && a.scratch) {
-            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 16;
+            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 20;
             dst[9] = t_end - stamp_entry;          // whole wave, shader clock
             dst[10] = rt_end - stamp_entry_rt;     // whole wave, constant 100 MHz clock
             dst[11] = stamp_entry_rt;              // start time (spread of the launch over the workgroups)

@@ -25,19 +25,20 @@ for _ in range(300):
     plan.execute(d_in, S * sw, W, *ptrs)
 ctx.synchronize()
 waves = 8 if n > 1024 else int(os.environ.get("SP_WAVES", "8"))
-cnt = 256 * waves * 16
+cnt = 256 * waves * 20
 buf = (ctypes.c_ulonglong * cnt)()
 lib = ctx.lib.L
 lib.sp_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 assert lib.sp_debug_read_stamps(ctx.h, buf, cnt) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(256, waves, 16).astype(np.float64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(256, waves, 20).astype(np.float64)
 names = ["head+decode", "pass1+xch1(+drain0)", "pass2+xch2", "pass3", "drain+barrier", "epilogue", "loop total", "start clock"]
 tot = a[:, :, 6].mean()
 print("%s: mean cycles per wave over the frame loop (%d frames per wave): %.0f" % (cfg, W // (256 * waves), tot))
 for k in range(6):
     print("  %-22s %9.0f  %5.1f %%   (min %.0f max %.0f over waves)" % (names[k], a[:, :, k].mean(), 100 * a[:, :, k].mean() / tot, a[:, :, k].min(), a[:, :, k].max()))
+waves_per_frame = max(1, n // 1024)
 print("  exact-edge path taken %.2f times per frame per wave (4 batches of 4 bins per frame); per-wave loop total min %.0f max %.0f"
-      % (a[:, :, 7].mean() / (W / (256.0 * waves)), a[:, :, 6].min(), a[:, :, 6].max()))
+      % (a[:, :, 7].mean() / (W * waves_per_frame / (256.0 * waves)), a[:, :, 6].min(), a[:, :, 6].max()))
 print("  by wave index (mean loop total):", np.round(a[:, :, 6].mean(axis=0)))
 for k in range(6):
     print("  by wave index %-20s" % names[k], np.round(a[:, :, k].mean(axis=0)))
@@ -45,6 +46,7 @@ ghz = a[:, :, 9].mean() / (a[:, :, 10].mean() * 10.0)
 print("  whole wave: %.0f shader cycles = %.2f us of the 100 MHz clock -> %.2f GHz; prologue %.0f cycles (%.2f us), loop %.0f (%.2f us), tail %.0f (%.2f us)"
       % (a[:, :, 9].mean(), a[:, :, 10].mean() / 100.0, ghz, a[:, :, 8].mean(), a[:, :, 8].mean() / ghz / 1e3, tot, tot / ghz / 1e3,
          (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean(), (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean() / ghz / 1e3))
+print("  prologue: arguments + first request %.0f cycles, tables arrive %.0f, zeroing + barrier %.0f" % (a[:, :, 16].mean(), a[:, :, 17].mean(), a[:, :, 18].mean()))
 hw = a[:, :, 13].astype(np.int64)
 print("  SIMD of wave index 0..7 (workgroup 0, 1, 100):", [list((hw[b] >> 4) & 3) for b in (0, 1, 100)], " wave slot:", list(hw[0] & 15))
 simd = (hw >> 4) & 3
