@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the Node drop-in leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostic: run the collectives of the N > 1 path with N = 1 too (one-rank RCCL group: exercises the nccl code path on a one-GPU box)")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     ap.add_argument("--merge-every", type=int, default=16,
@@ -147,8 +149,13 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                   # --force-dist started plainly: a one-rank group of its own
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -185,9 +192,9 @@ def main():
     # would put that on every step; M renders per collective leave the exchange itself as it is and divide the interference by M.)
     L = len(lut)
     P = L + 1000 + 2
-    M = max(1, args.merge_every) if world > 1 else 1
+    M = max(1, args.merge_every) if dist is not None else 1
     records = [torch.zeros(M * P, dtype=torch.int64, device=dev) for _ in range(2)]
-    gathered = [torch.zeros(world * M * P, dtype=torch.int64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.zeros(world * M * P, dtype=torch.int64, device=dev) for _ in range(2)] if dist is not None else None
     merged_buf = torch.zeros(P, dtype=torch.int64, device=dev)
     state = {"k": 0, "pending": None, "last": None}
 
@@ -323,7 +330,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
                          "frac_of_copy_ceiling_6290": achieved / 6290.0},
             "checks": {"c_hist_sum": hsum, "expected": world * W * n},
-            "renders_per_collective": M if world > 1 else None,
+            "renders_per_collective": M if dist is not None else None,
         }
         if gather_ms is not None:
             out["rgba_gather_ms"] = gather_ms

@@ -51,3 +51,11 @@ def test_two_ranks_on_one_gpu_merge_every_render(merge_every):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["renders_per_collective"] == merge_every
     assert d["checks"]["c_hist_sum"] == d["checks"]["expected"] == 2 * 16384 * 1024      # the LAST render's merged histogram
     assert d["rgba_gather_ms"] > 0
+
+
+def test_one_rank_rccl_group_runs_the_collectives():
+    """The N > 1 path's collectives through the nccl backend (RCCL) with a one-rank group: all the box has is one GPU."""
+    d = run_bench("--force-dist", "--steps", "40", "--warmup", "5", "--merge-every", "16", "--no-cpu-baseline", "--no-e2e")
+    assert d["n_gpus"] == 1 and d["renders_per_collective"] == 16
+    assert d["checks"]["c_hist_sum"] == d["checks"]["expected"] == 16384 * 1024
+    assert d["rgba_gather_ms"] > 0
