@@ -218,20 +218,31 @@ struct FrameMeet {
     unsigned addr;     // LDS byte address of the frame's counter (wave-uniform)
     unsigned target;   // the count once every wave of the frame has arrived the next time
     unsigned step;     // waves per frame
-    __device__ inline void operator()()
+    // One asm block each (a C loop around an atomic splits the kernel's big basic blocks and costs the register allocator 60+ spilled
+    // VGPRs).  arrive(): lane 0 adds one.  wait(): the wave polls until every wave of the frame has arrived as often as itself.
+    // A wave alternates arrive and wait strictly, so no wave is ever two arrivals ahead and the count cannot be reached early.
+    __device__ inline void arrive()
     {
         if constexpr (COUNTER) {
-            // one asm block (a C loop around an atomic splits the kernel's big basic blocks and costs the register allocator 60+
-            // spilled VGPRs): lane 0 adds one, then the wave polls the counter
-            target = (unsigned)__builtin_amdgcn_readfirstlane((int)(target + step));   // wave-uniform, kept in an SGPR
             unsigned long long save;
-            unsigned a_v, got_v, got_s;
+            unsigned a_v, one_v;
             asm volatile("v_mov_b32 %[a_v], %[addr]\n\t"
-                         "v_mov_b32 %[got_v], 1\n\t"
+                         "v_mov_b32 %[one_v], 1\n\t"
                          "s_mov_b64 %[save], exec\n\t"
                          "s_mov_b64 exec, 1\n\t"
-                         "ds_add_u32 %[a_v], %[got_v]\n\t"
-                         "s_mov_b64 exec, %[save]\n"
+                         "ds_add_u32 %[a_v], %[one_v]\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save), [a_v] "=&v"(a_v), [one_v] "=&v"(one_v)
+                         : [addr] "s"(addr)
+                         : "memory");
+        }
+    }
+    __device__ inline void wait()
+    {
+        if constexpr (COUNTER) {
+            target = (unsigned)__builtin_amdgcn_readfirstlane((int)(target + step));   // wave-uniform, kept in an SGPR
+            unsigned a_v, got_v, got_s;
+            asm volatile("v_mov_b32 %[a_v], %[addr]\n"
                          "L_sp_meet_%=:\n\t"
                          "ds_read_b32 %[got_v], %[a_v]\n\t"
                          "s_waitcnt lgkmcnt(0)\n\t"
@@ -239,12 +250,17 @@ struct FrameMeet {
                          "s_sub_i32 %[got_s], %[got_s], %[target]\n\t"
                          "s_cmp_lt_i32 %[got_s], 0\n\t"
                          "s_cbranch_scc1 L_sp_meet_%="
-                         : [save] "=&s"(save), [a_v] "=&v"(a_v), [got_v] "=&v"(got_v), [got_s] "=&s"(got_s)
+                         : [a_v] "=&v"(a_v), [got_v] "=&v"(got_v), [got_s] "=&s"(got_s)
                          : [addr] "s"(addr), [target] "s"(target)
                          : "memory", "scc");
         } else {
             spk::frame_sync<BLOCK_SYNC>();
         }
+    }
+    __device__ inline void operator()()
+    {
+        arrive();
+        wait();
     }
 };
 
@@ -261,6 +277,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     constexpr int NPASS = (LOG2N + 3) / 4;
 #ifndef SP_X_STAGED
 #define SP_X_STAGED 0
+#endif
+#ifndef SP_X_COUNTER_ALL
+#define SP_X_COUNTER_ALL 0
 #endif
 #ifndef SP_X_COUNTER_SYNC
 #define SP_X_COUNTER_SYNC 1
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const int fs = tid / T;                         // frame slot within a round
     const int tl = tid % T;                         // thread within the frame
     double *xbuf = s_xch + fs * (N + N / 16);
-    constexpr bool COUNTER_SYNC = SP_X_COUNTER_SYNC && BLOCK_SYNC && T < kThreads;   // a frame's waves are not the whole workgroup
+    constexpr bool COUNTER_SYNC = SP_X_COUNTER_SYNC && BLOCK_SYNC && (T < kThreads || SP_X_COUNTER_ALL);   // a frame's waves are not the whole workgroup
     FrameMeet<COUNTER_SYNC, BLOCK_SYNC> meet{
         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) unsigned int *)(s_done + 2 + fs)),
         0u, (unsigned)(T / 64)};
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     // non-temporal stores where a group's row pieces are whole 128-byte lines (below)
     auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, true, group_frames >= 32); };
     int drain_x0 = -1;
+    meet.arrive();   // the first re-distribution only waits (exchange<.., SECOND = false>)
 #ifdef SP_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64(), stamp_slow = 0;
     const unsigned long long stamp_begin = stamp_last;
@@ -714,8 +734,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
                 PassTw<WS1, 5, STAGED ? 4 : E1, TWMAX> tw1;
                 if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
-                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1, meet);
-                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1, meet);
+                exchange<0, WS1, BLOCK_SYNC, false>(re, b0, b1, meet);
+                exchange<0, WS1, BLOCK_SYNC, true>(im, b0, b1, meet);
                 exchange_wait(re, im);
                 if constexpr (DMA) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the buffer has returned
@@ -740,8 +760,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                     } else
 #endif
                     {
-                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2, meet);
-                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2, meet);
+                        exchange<WS1, WS2, BLOCK_SYNC, false>(re, b1, b2, meet);
+                        exchange<WS1, WS2, BLOCK_SYNC, true>(im, b1, b2, meet);
                 exchange_wait(re, im);
                     }
                     SP_STAMP(2)   // second pass, second exchange
@@ -753,8 +773,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
                         PassTw<WS3, 13, LOG2N, TWMAX> tw3;
                         load_pass_tw(tw3, tl, s_tw, tw);
-                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3, meet);
-                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3, meet);
+                        exchange<WS2, WS3, BLOCK_SYNC, false>(re, b2, b3, meet);
+                        exchange<WS2, WS3, BLOCK_SYNC, true>(im, b2, b3, meet);
                 exchange_wait(re, im);
                         fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
@@ -764,7 +784,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 
             if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS (as k_lds_r16)
                 double pp[16];
-                meet();
+                meet.wait();   // (announced after the last re-distribution's reads)
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
                 meet();
@@ -801,6 +821,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         im[e] = 0.5 * (pp[e] + oi);
                     }
                 }
+                meet.arrive();   // for the next frame's first re-distribution
             }
 
             if (drain_x0 >= 0) {

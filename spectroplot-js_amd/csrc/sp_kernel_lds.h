@@ -222,20 +222,30 @@ __device__ inline void frame_sync()
 
 // How the threads of one frame meet around a re-distribution: frame_sync<BLOCK_SYNC>() as a function object (the default), or
 // a kernel's own (k_frames: the waves of a frame meet through an LDS counter).
+// A sync has two halves: arrive() announces "everything I issued so far may be relied on", wait() blocks until every partner has
+// announced; operator() is both.  Where a wave's reads are followed by a pass of arithmetic before the buffer is written again, the
+// exchange announces right after the reads and only waits before the writes (the default object cannot split: its arrive() does nothing
+// and its wait() is the whole sync).
 template <bool BLOCK_SYNC>
 struct FrameSyncDefault {
     __device__ inline void operator()() const { frame_sync<BLOCK_SYNC>(); }
+    __device__ inline void arrive() const {}
+    __device__ inline void wait() const { frame_sync<BLOCK_SYNC>(); }
 };
 
 // Re-distribute the 16 values of every thread from window WS_FROM to window WS_TO through the frame's LDS buffer.
 // from / to point at this thread's element 0 under the respective window.
-template <int WS_FROM, int WS_TO, bool BLOCK_SYNC, class SYNC = FrameSyncDefault<BLOCK_SYNC>>
+// SECOND: the imaginary parts, which follow the real parts through the same buffer: the sync before their writes comes right after
+// the reads of the real parts (nothing to split); the sync before the writes of the real parts was announced after the previous
+// re-distribution's last reads.
+template <int WS_FROM, int WS_TO, bool BLOCK_SYNC, bool SECOND, class SYNC = FrameSyncDefault<BLOCK_SYNC>>
 __device__ inline void exchange(double (&v)[16], double *from, const double *to, SYNC &&sync = SYNC())   // from / to alias: no __restrict__
 {
 #ifdef SP_ABL_NOEXCH
     return;
 #endif
-    sync();   // previous readers are done with the buffer
+    if constexpr (SECOND) sync();   // previous readers are done with the buffer
+    else sync.wait();
 #pragma unroll
     for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
     sync();
@@ -249,6 +259,7 @@ __device__ inline void exchange(double (&v)[16], double *from, const double *to,
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = to[win_off(e, WS_TO)];
 #endif
+    if constexpr (SECOND) sync.arrive();   // (a wave's LDS operations execute in order: the announcement follows the reads)
 }
 
 // The compiler does not see the reads of exchange() when they are written as asm (SP_X_ASM_READS): every value passes through
@@ -705,8 +716,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
                 PassTw<WS1, 5, STAGED ? 4 : E1> tw1;
                 if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
-                exchange<0, WS1, BLOCK_SYNC>(re, b0, b1);
-                exchange<0, WS1, BLOCK_SYNC>(im, b0, b1);
+                exchange<0, WS1, BLOCK_SYNC, false>(re, b0, b1);
+                exchange<0, WS1, BLOCK_SYNC, true>(im, b0, b1);
                 exchange_wait(re, im);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
@@ -721,8 +732,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         exchange_permlane<LOG2N>(re);      // no LDS: v_permlane16_swap / v_permlane32_swap
                         exchange_permlane<LOG2N>(im);
                     } else {
-                        exchange<WS1, WS2, BLOCK_SYNC>(re, b1, b2);
-                        exchange<WS1, WS2, BLOCK_SYNC>(im, b1, b2);
+                        exchange<WS1, WS2, BLOCK_SYNC, false>(re, b1, b2);
+                        exchange<WS1, WS2, BLOCK_SYNC, true>(im, b1, b2);
                 exchange_wait(re, im);
                     }
                     if constexpr (STAGED) fft_pass_staged<WS2, 9, E2>(re, im, tl, s_tw, tw);
@@ -732,8 +743,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_r16(const FrameArgs a, cons
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
                         PassTw<WS3, 13, LOG2N> tw3;
                         load_pass_tw(tw3, tl, s_tw, tw);
-                        exchange<WS2, WS3, BLOCK_SYNC>(re, b2, b3);
-                        exchange<WS2, WS3, BLOCK_SYNC>(im, b2, b3);
+                        exchange<WS2, WS3, BLOCK_SYNC, false>(re, b2, b3);
+                        exchange<WS2, WS3, BLOCK_SYNC, true>(im, b2, b3);
                 exchange_wait(re, im);
                         fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
