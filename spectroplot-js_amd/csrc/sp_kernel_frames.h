@@ -218,6 +218,9 @@ struct FrameMeet {
     unsigned addr;     // LDS byte address of the frame's counter (wave-uniform)
     unsigned target;   // the count once every wave of the frame has arrived the next time
     unsigned step;     // waves per frame
+#ifdef SP_STAMPS
+    unsigned long long spent = 0;   // shader clocks inside wait()
+#endif
     // One asm block each (a C loop around an atomic splits the kernel's big basic blocks and costs the register allocator 60+ spilled
     // VGPRs).  arrive(): lane 0 adds one.  wait(): the wave polls until every wave of the frame has arrived as often as itself.
     // A wave alternates arrive and wait strictly, so no wave is ever two arrivals ahead and the count cannot be reached early.
@@ -242,6 +245,10 @@ struct FrameMeet {
         if constexpr (COUNTER) {
             target = (unsigned)__builtin_amdgcn_readfirstlane((int)(target + step));   // wave-uniform, kept in an SGPR
             unsigned a_v, got_v, got_s;
+#ifdef SP_STAMPS
+            unsigned long long t0_, t1_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
+#endif
             asm volatile("v_mov_b32 %[a_v], %[addr]\n"
                          "L_sp_meet_%=:\n\t"
                          "ds_read_b32 %[got_v], %[a_v]\n\t"
@@ -253,6 +260,10 @@ struct FrameMeet {
                          : [a_v] "=&v"(a_v), [got_v] "=&v"(got_v), [got_s] "=&s"(got_s)
                          : [addr] "s"(addr), [target] "s"(target)
                          : "memory", "scc");
+#ifdef SP_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+            spent += t1_ - t0_;
+#endif
         } else {
             spk::frame_sync<BLOCK_SYNC>();
         }
@@ -966,6 +977,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             dst[16] = pro_stamp[0] - stamp_entry;
             dst[17] = pro_stamp[1] - pro_stamp[0];
             dst[18] = stamp_begin - pro_stamp[1];
+            dst[19] = meet.spent;
             dst[15] = loop_end;
         }
     }

@@ -47,6 +47,7 @@ print("  whole wave: %.0f shader cycles = %.2f us of the 100 MHz clock -> %.2f G
       % (a[:, :, 9].mean(), a[:, :, 10].mean() / 100.0, ghz, a[:, :, 8].mean(), a[:, :, 8].mean() / ghz / 1e3, tot, tot / ghz / 1e3,
          (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean(), (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean() / ghz / 1e3))
 print("  prologue: arguments + first request %.0f cycles, tables arrive %.0f, zeroing + barrier %.0f" % (a[:, :, 16].mean(), a[:, :, 17].mean(), a[:, :, 18].mean()))
+print("  inside the frame meetings (n >= 2048): %.0f cycles per wave = %.1f %% of the loop; by wave:" % (a[:, :, 19].mean(), 100 * a[:, :, 19].mean() / tot), np.round(a[:, :, 19].mean(axis=0)))
 hw = a[:, :, 13].astype(np.int64)
 print("  SIMD of wave index 0..7 (workgroup 0, 1, 100):", [list((hw[b] >> 4) & 3) for b in (0, 1, 100)], " wave slot:", list(hw[0] & 15))
 simd = (hw >> 4) & 3
