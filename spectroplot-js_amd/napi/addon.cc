@@ -155,12 +155,18 @@ struct HostPool {
 };
 HostPool g_pool;
 
+// What V8 is told a reply image weighs: its size up to 16 MiB.  At full weight a config-2 reply (64 MiB) reaches the collector's
+// external-memory limit by itself: one mark-sweep per message (1.2 ms each, `node --trace-gc tools/js_dropin_bench.js`).  Capped, the
+// collector runs about every fourth large reply - as it does for 16 MiB replies anyway - and the pool holds five or six blocks
+// instead of two; the blocks still return by collection only.
+constexpr size_t kReplyWeightCap = (size_t)16 << 20;
+inline int64_t reply_weight(size_t size) { return (int64_t)(size < kReplyWeightCap ? size : kReplyWeightCap); }
 struct PoolTag { size_t size; bool pinned; };
 void pool_free_cb(napi_env env, void *data, void *hint)
 {
     PoolTag *t = (PoolTag *)hint;
     int64_t total = 0;
-    napi_adjust_external_memory(env, -(int64_t)t->size, &total);
+    napi_adjust_external_memory(env, -reply_weight(t->size), &total);
     g_pool.give(data, t->size, t->pinned);
     delete t;
 }
@@ -287,7 +293,7 @@ napi_value make_reply(napi_env env, Job *j)
         PoolTag *tag = new PoolTag{j->rgba_size, j->rgba_pinned};
         if (napi_create_external_arraybuffer(env, j->rgba, 4 * W * n, pool_free_cb, tag, &ab) == napi_ok) {
             int64_t total = 0;
-            napi_adjust_external_memory(env, (int64_t)j->rgba_size, &total);
+            napi_adjust_external_memory(env, reply_weight(j->rgba_size), &total);
             j->rgba = nullptr;
             napi_set_named_property(env, out, "rgba", ab);
         } else {
