@@ -10,12 +10,19 @@
 //     index k*n/16 is scaled by a power of two before the division by n), so they are literals: no LDS reads, no registers;
 //     the butterflies whose twiddle is (1, 0) skip their products when the frame is finite (integer formats always; float
 //     frames after one f32 multiply-add per raw word), the ones whose sine is exactly 1 skip two products always;
-//   * both re-distributions go through LDS (the register transpose with v_permlane swaps cost 64 x 8 cycles per frame);
+//   * the re-distribution between passes goes through a padded, wave-private LDS buffer; at n = 512 / 1024 the second one is a
+//     register transpose (v_permlane16_swap / v_permlane32_swap: what it costs the VALU the LDS round trip costs the LDS pipe);
 //   * epilogue: colour index and centi-bel level are floor(a + b*log2(|X|^2)) in f32; a lane is sent to the exact edge tables
-//     only if its f32 value lies within a proven error margin of an integer (a few lanes in a thousand), so the common path has
-//     no LDS read, no f64 compare and no data-dependent bank conflict; clipped colour indices land in lane-private histogram
-//     words through lane-dependent clamp bounds instead of compare / select / ballot sequences.
+//     only if its f32 value lies within a proven error margin of an integer (a few lanes in ten thousand), so the common path has
+//     no LDS read and no f64 compare; one histogram atomic per pixel on the merged cell (colour index + level), which the
+//     finish kernel turns back into the two histograms;
+//   * n >= 2048 (a frame spans several waves): the waves of a frame meet through an LDS counter, announced early and waited for
+//     late where the dataflow allows, instead of the workgroup barrier;
+//   * the workgroup's last write-out is split between the first and the second waves of the SIMDs (n = 1024): the first ones
+//     finish ~7 us earlier and write their half meanwhile.
 // Everything else (input prefetch, exchange buffer, tile and write-out, per-frame extremes) follows k_lds_r16.
+// Macros SP_X_* select measured alternatives in libraries built by tools/build_variant.sh; SP_ABL_* remove a
+// piece for cost attribution (results invalid); SP_STAMPS adds the per-wave clocks tools/stamps.py reads.  None is set in the product.
 #pragma once
 
 #include <cstdio>
