@@ -305,6 +305,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifndef SP_X_HALVES
 #define SP_X_HALVES 1
 #endif
+#ifndef SP_X_BIG8
+#define SP_X_BIG8 2   // 8-byte samples at n >= 2048: 1 = stage-by-stage twiddles, 2 = samples requested at frame start (no spills; cf32 n = 2048: 411 -> 358 us per 32 768 frames)
+#endif
 #ifndef SP_X_LATEPF
 #define SP_X_LATEPF 0
 #endif
@@ -316,10 +319,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #else
 #define SP_PRO_STAMP(k)
 #endif
-    constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED;  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
+    constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED || (SP_X_BIG8 & 1 && PFB == 8 && LOG2N >= 11);  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
     // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
     // requested when it starts and the other waves of the SIMD cover the latency
-    constexpr bool LATE_PF = WAVES > 8 || SP_X_LATEPF;
+    constexpr bool LATE_PF = WAVES > 8 || SP_X_LATEPF || (SP_X_BIG8 & 2 && PFB == 8 && LOG2N >= 11);
     // 3 waves per SIMD at n = 1024 (one wave per frame): the next frame's raw samples travel HBM -> LDS by LDS-DMA
     // (global_load_lds_dwordx4: no registers) into the frame's exchange buffer, which is idle once the first exchange has been
     // read back (the second one is a register transpose); the taper comes from L2 at the top of a frame.
