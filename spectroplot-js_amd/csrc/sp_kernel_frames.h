@@ -30,6 +30,9 @@
 #include "sp_kernel_lds.h"
 
 // experiment switches of the large-n layout (defaults = the shipped kernel)
+#ifndef SP_X_BIG_FROM
+#define SP_X_BIG_FROM 2048
+#endif
 #ifndef SP_X_TWMAX_BIG
 #define SP_X_TWMAX_BIG 9
 #endif
@@ -82,10 +85,11 @@ __host__ __device__ inline bool frames_kernel_supports(int n, int waves)
     return T <= threads && threads % T == 0;
 }
 
-// n >= 4096: the twiddle tables of stages 1-9 only stay in LDS (stage 10 joins 11-13 in L2: two more loads per thread and frame),
-// which makes room for a 64 KiB tile: 16 / 8 frames per group instead of 8 / 4, i.e. 64 / 32-byte pieces of the image rows instead of
-// 32 / 16 and half as many group barriers (config 5 wrote 2.1 x its image with 16-byte pieces)
-__host__ __device__ inline constexpr int frames_tw_max_stage(int n) { return n >= 4096 ? SP_X_TWMAX_BIG : kLdsTwMaxStage; }
+// n >= 2048: the twiddle tables of stages 1-9 only stay in LDS (stage 10 joins the later ones in L2: two more loads per thread and
+// frame), which makes room for a 64 KiB tile: 32 / 16 / 8 frames per group instead of 16 / 8 / 4, i.e. 128 / 64 / 32-byte pieces of
+// the image rows and half as many group barriers (config 5 wrote 2.1 x its image with 16-byte pieces; config 3: -0.7 %, cf32 at
+// n = 2048: -5 %, config 5: -5 %)
+__host__ __device__ inline constexpr int frames_tw_max_stage(int n) { return n >= SP_X_BIG_FROM ? SP_X_TWMAX_BIG : kLdsTwMaxStage; }
 __host__ __device__ inline constexpr int frames_tw_entries(int n) { return n < (1 << frames_tw_max_stage(n)) ? n : (1 << frames_tw_max_stage(n)); }
 
 // frames per output group (tile height): a multiple of the frames per round and of 4 (the write-out handles frame quads)
@@ -94,7 +98,7 @@ __host__ __device__ inline int group_frames_for(int n, int want, int threads)
     const int fpb = threads * 16 / n;
     int unit = fpb;
     while (unit % 4) unit *= 2;          // lcm(fpb, 4) for fpb in {1, 2, 3, 6, 12, ...}
-    int cap = (n >= 4096 ? SP_X_TILE_BIG : 32768) / n;
+    int cap = (n >= SP_X_BIG_FROM ? SP_X_TILE_BIG : 32768) / n;
     if (cap > want) cap = want;
     int f = cap / unit * unit;
     if (f < unit) f = unit;
