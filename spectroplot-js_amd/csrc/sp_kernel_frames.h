@@ -312,6 +312,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #ifndef SP_X_BIG8
 #define SP_X_BIG8 2   // 8-byte samples at n >= 2048: 1 = stage-by-stage twiddles, 2 = samples requested at frame start (no spills; cf32 n = 2048: 411 -> 358 us per 32 768 frames)
 #endif
+#ifndef SP_X_BATCH
+#define SP_X_BATCH 2   // bins per epilogue batch (one exact-path branch per batch): 2 measured best (4: config 4 +3 %, config 5 +2.5 %; 8: +5 %; 16: spills)
+#endif
 #ifndef SP_X_LATEPF
 #define SP_X_LATEPF 0
 #endif
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             // scale (sp_host.cpp); a and the clamp bounds are lowered by m, so floor(t) is exact unless fract(t) >= 1 - 2m.
             // Lanes past that threshold (and centi-bel values at or beyond the ends of the scale, +-inf and NaN among them, whose
             // clamp bounds lie past it by construction) take the exact edge compare.
-            // four independent min / max chains (one per bin of a batch): a dependent f64 operation waits several issue slots
+            // four independent min / max chains: a dependent f64 operation waits several issue slots
             double mn4[4] = {spjs::inf(), spjs::inf(), spjs::inf(), spjs::inf()}, mx4[4] = {0.0, 0.0, 0.0, 0.0};
             uint32_t *trow = (uint32_t *)(s_tile + fr * tile_pitch + tl * 16);
 #ifdef SP_ABL_NOEPI
@@ -871,50 +874,52 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #else
             if (live) {
 #endif
-                // four bins at a time: four independent chains for the VALU, one branch, one packed tile dword
+                constexpr int EB = SP_X_BATCH;   // bins per batch
+                uint32_t tile_word = 0;          // four colour bytes per tile dword
+                // a batch of bins at a time: independent chains for the VALU, one branch per batch, four colour bytes per tile dword
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    double abs2[4];
-                    float tg[4], tc[4];
-                    int gi[4], cell[4];
-                    bool risky[4];
+                for (int q = 0; q < 16 / EB; q++) {
+                    double abs2[EB];
+                    float tg[EB], tc[EB];
+                    int gi[EB], cell[EB];
+                    bool risky[EB];
                     float worst = 0.0f;   // largest fractional part of the batch, either scale
                     // written stage by stage: the four chains are independent, and every step of a chain waits on the one before
-                    float l2[4];
+                    float l2[EB];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) abs2[k] = re[4 * q + k] * re[4 * q + k] + im[4 * q + k] * im[4 * q + k];   // worker.js:92
+                    for (int k = 0; k < EB; k++) abs2[k] = re[EB * q + k] * re[EB * q + k] + im[EB * q + k] * im[EB * q + k];   // worker.js:92
 #pragma unroll
-                    for (int k = 0; k < 4; k++) l2[k] = (float)abs2[k];
+                    for (int k = 0; k < EB; k++) l2[k] = (float)abs2[k];
 #pragma unroll
 #ifndef SP_ABL_NOLOG
-                    for (int k = 0; k < 4; k++) l2[k] = __log2f(l2[k]);
+                    for (int k = 0; k < EB; k++) l2[k] = __log2f(l2[k]);
 #else
-                    for (int k = 0; k < 4; k++) l2[k] = l2[k] * 3.0f;
+                    for (int k = 0; k < EB; k++) l2[k] = l2[k] * 3.0f;
 #endif
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
 #ifndef SP_ABL_NOMM
-                        mn4[k] = min_raw(mn4[k], abs2[k]);
-                        mx4[k] = max_raw(mx4[k], abs2[k]);
+                        mn4[k & 3] = min_raw(mn4[k & 3], abs2[k]);
+                        mx4[k & 3] = max_raw(mx4[k & 3], abs2[k]);
 #endif
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
                         tg[k] = fmaf(g_b, l2[k], g_a);
                         tc[k] = fmaf(c_b, l2[k], c_a);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
                         tg[k] = __builtin_amdgcn_fmed3f(tg[k], g_lo, g_hi);
                         tc[k] = __builtin_amdgcn_fmed3f(tc[k], c_lo, c_hi);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
                         gi[k] = floor_to_int(tg[k]);                                   // colour index
                         cell[k] = floor_to_int(tc[k]);                                 // level (= 999 - centi-bel bin)
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
 #ifndef SP_ABL_NORISKY
                         // (the clamps have turned a NaN into a bound, so the fractional parts are numbers; one threshold, the
                         // smaller of the two, serves both scales)
@@ -924,24 +929,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                     }
                     if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
+                        for (int k = 0; k < EB; k++)
                             risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < thr) || !(__builtin_amdgcn_fractf(tc[k]) < thr);
 #ifdef SP_STAMPS
                         stamp_slow++;
 #endif
                         // nearest edge on either scale for every lane (one batch of reads, one wait), then one exact comparison
                         // each; only the risky lanes keep the result (edges: sp_host.h Thresholds)
-                        int rg[4], rc[4];
-                        double eg[4], ec[4];
+                        int rg[EB], rc[EB];
+                        double eg[EB], ec[EB];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < EB; k++) {
                             rg[k] = min(max((int)rintf(tg[k] + g_m), 1), cmax);
                             rc[k] = min(max((int)rintf(tc[k] + c_m), 1), SP_CB_HIST_SIZE);
                             eg[k] = edge_g[rg[k]];
                             ec[k] = edge_cb[rc[k]];
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < EB; k++) {
                             int g = abs2[k] >= eg[k] ? rg[k] : rg[k] - 1;
                             int c = g + (abs2[k] >= ec[k] ? rc[k] : rc[k] - 1);
                             // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
@@ -956,10 +961,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         }
                     }
 #ifndef SP_ABL_NOTILE
-                    trow[q] = (uint32_t)gi[0] | ((uint32_t)gi[1] << 8) | ((uint32_t)gi[2] << 16) | ((uint32_t)gi[3] << 24);
+#pragma unroll
+                    for (int k = 0; k < EB; k++) {
+                        const int e = EB * q + k;                 // compile-time after unrolling
+                        tile_word = (e & 3) == 0 ? (uint32_t)gi[k] : tile_word | ((uint32_t)gi[k] << (8 * (e & 3)));
+                        if ((e & 3) == 3) trow[e >> 2] = tile_word;
+                    }
 #endif
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < EB; k++) {
 #ifndef SP_ABL_NOHIST
                         atomicAdd(&s_cells[cell[k]], 1u);
 #else

@@ -37,7 +37,7 @@ print("%s: mean cycles per wave over the frame loop (%d frames per wave): %.0f" 
 for k in range(6):
     print("  %-22s %9.0f  %5.1f %%   (min %.0f max %.0f over waves)" % (names[k], a[:, :, k].mean(), 100 * a[:, :, k].mean() / tot, a[:, :, k].min(), a[:, :, k].max()))
 waves_per_frame = max(1, n // 1024)
-print("  exact-edge path taken %.2f times per frame per wave (4 batches of 4 bins per frame); per-wave loop total min %.0f max %.0f"
+print("  exact-edge path taken %.2f times per frame per wave (8 batches of 2 bins per frame); per-wave loop total min %.0f max %.0f"
       % (a[:, :, 7].mean() / (W * waves_per_frame / (256.0 * waves)), a[:, :, 6].min(), a[:, :, 6].max()))
 print("  by wave index (mean loop total):", np.round(a[:, :, 6].mean(axis=0)))
 for k in range(6):
