@@ -143,6 +143,36 @@ double first_true(uint64_t lo, Pred pred)
     return spjs::from_bits(hi);
 }
 
+// The same answer, found from a guess: the step sits within a few ulps of where the real-valued formula puts it, so a bracket of
+// 2^12 ulps around the guess (widened by 16 x while it does not hold the step) and ~13 halvings replace the 62 halvings over all
+// positive doubles.  Any failure of the bracket search falls back to the full search; pred(lo) is known to be false.
+template <typename Pred>
+double first_true_near(uint64_t lo, double guess, Pred pred)
+{
+    if (pred(spjs::from_bits(lo))) return spjs::from_bits(lo);
+    if (!(guess > 0.0) || guess == spjs::inf()) return first_true(lo, pred);
+    const uint64_t gb = spjs::bits(guess);
+    for (uint64_t delta = (uint64_t)1 << 12; delta < ((uint64_t)1 << 56); delta <<= 4) {
+        uint64_t l = gb > delta ? gb - delta : kMinPos, h = gb + delta;
+        if (l < lo) l = lo;
+        if (h > kMaxFinite) h = kMaxFinite;
+        if (h <= l) return first_true(lo, pred);
+        const bool pl = l == lo ? false : pred(spjs::from_bits(l));
+        if (pl) continue;                              // the step is below the bracket
+        if (!pred(spjs::from_bits(h))) {
+            if (h == kMaxFinite) return spjs::inf();
+            continue;                                  // the step is above the bracket
+        }
+        while (h - l > 1) {
+            const uint64_t mid = l + (h - l) / 2;
+            if (pred(spjs::from_bits(mid))) h = mid;
+            else l = mid;
+        }
+        return spjs::from_bits(h);
+    }
+    return first_true(lo, pred);
+}
+
 }  // namespace
 
 Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
@@ -151,9 +181,17 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
     t.gray_edge.assign((size_t)lut_len, 0.0);
     t.cb_edge.assign(SP_CB_HIST_SIZE + 1, 0.0);
 
+    // first guesses: dbfs = 5*log10(2)*log2(abs2) + block_norm_db + gain
+    const double c = 5.0 * 0.30102999566398120;
+    const double per_db = (double)lut_len / pm.range;
+    // real-valued position of abs2 on the two scales: colour 0.5 + color_max + per_db*dbfs, level 999.5 + 10*rel_db; step g / j is
+    // where the position reaches g / j
+    const double pos_g_a = 0.5 + pm.color_max + per_db * (pm.block_norm_db + pm.gain), pos_g_b = per_db * c;
+    const double pos_c_a = (SP_CB_HIST_SIZE - 0.5) + 10.0 * pm.block_norm_db, pos_c_b = 10.0 * c;
+
     uint64_t lo = kMinPos;
     for (int32_t g = 1; g < lut_len; g++) {
-        const double e = first_true(lo, [&](double a) { return pm.gray(a) >= g; });
+        const double e = first_true_near(lo, std::exp2(((double)g - pos_g_a) / pos_g_b), [&](double a) { return pm.gray(a) >= g; });
         t.gray_edge[(size_t)g] = e;
         if (e != spjs::inf()) lo = spjs::bits(e);   // edges are non-decreasing
     }
@@ -164,14 +202,11 @@ Thresholds build_thresholds(const PixelMath &pm, int32_t lut_len)
     };
     lo = kMinPos;
     for (int32_t j = 1; j <= SP_CB_HIST_SIZE; j++) {
-        const double e = first_true(lo, [&](double a) { return level(a) >= j; });
+        const double e = first_true_near(lo, std::exp2(((double)j - pos_c_a) / pos_c_b), [&](double a) { return level(a) >= j; });
         t.cb_edge[(size_t)j] = e;
         if (e != spjs::inf()) lo = spjs::bits(e);
     }
 
-    // first guesses: dbfs = 5*log10(2)*log2(abs2) + block_norm_db + gain
-    const double c = 5.0 * 0.30102999566398120;
-    const double per_db = (double)lut_len / pm.range;
     // gray  = floor(0.5 + color_max + per_db*dbfs)  -> guess floor(color_max + per_db*dbfs)   in {gray-1, gray}
     // level = floor(999.5 + 10*rel_db) (off the edges) -> guess floor(999 + 10*rel_db)       in {level-1, level}
     t.gray_a = (float)(pm.color_max + per_db * (pm.block_norm_db + pm.gain));

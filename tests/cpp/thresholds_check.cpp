@@ -1,0 +1,65 @@
+// Test harness (built and run by tests/test_thresholds_cpu.py): the edge tables of sphost::build_thresholds against an independent
+// full bisection over all positive doubles with the same public pixel arithmetic (sphost::PixelMath::gray / centibel), for a
+// spread of gains, ranges, norms and LUT lengths.  Prints the number of differing edges and the time per table set.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "sp_host.h"
+
+static double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static uint64_t to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+template <typename Pred>
+static double full_search(uint64_t lo, Pred pred)
+{
+    if (pred(from_bits(lo))) return from_bits(lo);
+    uint64_t hi = 0x7fefffffffffffffull;
+    if (!pred(from_bits(hi))) return from_bits(0x7ff0000000000000ull);
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (pred(from_bits(mid))) hi = mid;
+        else lo = mid;
+    }
+    return from_bits(hi);
+}
+
+int main()
+{
+    const double gains[] = {6.0, 0.0, -10.0, 59.0, 2500.0, -2500.0, 33.3};
+    const double ranges[] = {30.0, 6.0, 45.5, 120.0, 3000.0};
+    const double norms[] = {1.0 / 512.0, 1.0, 1e-6, 37.5};
+    const int luts[] = {256, 2, 3, 17, 255, 300};
+    long bad = 0, sets = 0;
+    double ms = 0;
+    for (double gain : gains)
+        for (double range : ranges)
+            for (double bn : norms)
+                for (int lut_len : luts) {
+                    sphost::PixelMath pm(bn, gain, range, lut_len);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const sphost::Thresholds th = sphost::build_thresholds(pm, lut_len);
+                    ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    sets++;
+                    uint64_t lo = 1;
+                    for (int g = 1; g < lut_len; g++) {
+                        const double e = full_search(lo, [&](double a) { return pm.gray(a) >= g; });
+                        if (to_bits(e) != to_bits(th.gray_edge[(size_t)g])) bad++;
+                        if (e != from_bits(0x7ff0000000000000ull)) lo = to_bits(e);
+                    }
+                    auto level = [&](double a) {
+                        const int32_t cb = pm.centibel(a);
+                        if (cb < 0) return SP_CB_HIST_SIZE;
+                        return SP_CB_HIST_SIZE - 1 - (cb > SP_CB_HIST_SIZE - 1 ? SP_CB_HIST_SIZE - 1 : cb);
+                    };
+                    lo = 1;
+                    for (int j = 1; j <= SP_CB_HIST_SIZE; j++) {
+                        const double e = full_search(lo, [&](double a) { return level(a) >= j; });
+                        if (to_bits(e) != to_bits(th.cb_edge[(size_t)j])) bad++;
+                        if (e != from_bits(0x7ff0000000000000ull)) lo = to_bits(e);
+                    }
+                }
+    printf("%ld table sets, %ld differing edges, %.3f ms per set\n", sets, bad, ms / sets);
+    return bad ? 1 : 0;
+}
