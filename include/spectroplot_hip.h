@@ -13,6 +13,7 @@
  *   sp_window                lib/windows.js:14-88       named taper generators (optional sugar; the wire carries arrays)
  *   sp_cmap, sp_cmap_key     lib/cube1cmap.js, lib/matplotlibcmaps.js, lib/soxcmap.js, lib/naivecmap.js, lib/utils.js:25-40
  *   sp_render_named          lib/spectroplot.js:1113-1146, 1213-1226   the caller's message assembly from option names
+ *   sp_named_resolve         lib/spectroplot.js:238-264, lib/utils.js:25-40   option name -> generator / table entry, with the defaults
  *   sp_twiddles              lib/fft_nayuki.js:42-47    cos/sin tables (exposed for tests)
  *   sp_plan_create           lib/worker.js:30-62        per-request constants + the cached FFT object
  *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
@@ -155,6 +156,17 @@ typedef struct sp_named_request {
     double gain, range;
 } sp_named_request;
 int sp_render_named(sp_context *ctx, const sp_named_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+/*
+ * What the two option names of a named request resolve to (no device needed): the taper's plain name as sp_window takes it, the
+ * colour map's key and its entry count (the caller sizes the reply's c_hist with it).  Any output may be NULL.
+ */
+int sp_named_resolve(const char *window, const char *cmap, const char **window_name, const char **cmap_key, int32_t *lut_len);
+/*
+ * How many plans - i.e. sets of taper / twiddle / LUT / threshold tables evaluated on the host and uploaded to the device - this
+ * context has built so far, through sp_plan_create, sp_render or sp_render_named.  A request that repeats the previous one's
+ * constants (sp_render: the same arrays by value; sp_render_named: the same names and numbers) does not add to it.
+ */
+int sp_context_plan_creations(const sp_context *ctx, int64_t *count);
 
 /* Pre-evaluated request constants resident on the device: twiddles, taper, RGBA LUT, threshold tables. */
 int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **plan);

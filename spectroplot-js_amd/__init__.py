@@ -7,6 +7,7 @@ and there is no CPU fallback: importing works anywhere, but every compute call n
 
 Load it with `importlib` (the directory name has a hyphen), e.g. `from __graft_entry__ import load_package`.
 """
+from . import binding  # noqa: F401
 from .binding import (Library, Context, Plan, SpectroplotError, FORMATS, lib_path, build_library,  # noqa: F401
                       parse_format, slice_bounds, window, twiddles)
 from .worker import HipWorker, render_sliced  # noqa: F401

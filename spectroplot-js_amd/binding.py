@@ -29,6 +29,11 @@ class _Request(C.Structure):
                 ("range", C.c_double), ("windowc", C.c_void_p), ("lut_rgb", C.c_void_p)]
 
 
+class _NamedRequest(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("window", C.c_char_p), ("cmap", C.c_char_p), ("n", C.c_int32), ("channel_mode", C.c_int32),
+                ("waterfall", C.c_int32), ("gain", C.c_double), ("range", C.c_double)]
+
+
 class _Reply(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("gauge_mins", C.c_void_p), ("gauge_maxs", C.c_void_p), ("gauge_amps", C.c_void_p),
                 ("c_hist", C.c_void_p), ("cb_hist", C.c_void_p), ("dbfs_minmax", C.c_void_p)]
@@ -82,6 +87,9 @@ class Library:
         L.sp_context_set_stream.argtypes = [vp, vp]
         L.sp_context_synchronize.argtypes = [vp]
         L.sp_render.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply)]
+        L.sp_render_named.argtypes = [vp, C.POINTER(_NamedRequest), vp, sz, i32, C.POINTER(_Reply)]
+        L.sp_named_resolve.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i32)]
+        L.sp_context_plan_creations.argtypes = [vp, C.POINTER(C.c_int64)]
         L.sp_plan_create.argtypes = [vp, C.POINTER(_Request), C.POINTER(vp)]
         L.sp_plan_destroy.argtypes = [vp]
         L.sp_plan_destroy.restype = None
@@ -146,6 +154,15 @@ def twiddles(n):
     s = np.empty(max(n // 2, 1), dtype=np.float64)
     lib.check(lib.L.sp_twiddles(n, c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
     return c[:n // 2], s[:n // 2]
+
+
+def named_resolve(window, cmap):
+    """(taper name as sp_window takes it, colour-map key, entry count) for two option names, defaults included
+    (lib/spectroplot.js:238-264, lib/utils.js:25-40)."""
+    w, k, n = C.c_char_p(), C.c_char_p(), C.c_int32()
+    lib = Library.get()
+    lib.check(lib.L.sp_named_resolve(str(window).encode(), str(cmap).encode(), C.byref(w), C.byref(k), C.byref(n)))
+    return w.value.decode(), k.value.decode(), n.value
 
 
 def _make_request(fmt_id, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall):
@@ -251,6 +268,30 @@ class Context:
         self._chk(self.lib.L.sp_render(self.h, C.byref(req), p(data), data.size, W, C.byref(rep)))
         out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])
         return out
+
+    def render_named(self, fmt, data, n, window, cmap, gain, rng, width, channel_mode=False, waterfall=False):
+        """The request by option names, as the reference's caller assembles its message (lib/spectroplot.js:1113-1146): the library
+        evaluates taper, block_norm and colour map (ends forced) itself and keeps the plan while names and numbers repeat."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        W = int(width)
+        L = named_resolve(window, cmap)[2]
+        req = _NamedRequest(str(fmt).encode(), str(window).encode(), str(cmap).encode(), int(n), int(bool(channel_mode)),
+                            int(bool(waterfall)), float(gain), float(rng))
+        out = {"rgba": np.zeros(4 * max(W, 0) * n, np.uint8), "gauge_mins": np.zeros(max(W, 0), np.uint8),
+               "gauge_maxs": np.zeros(max(W, 0), np.uint8), "gauge_amps": np.zeros(max(W, 0), np.uint8),
+               "c_hist": np.zeros(L, np.uint64), "cB_hist": np.zeros(SP_CB_HIST_SIZE, np.uint64)}
+        mm = np.array([0.0, -200.0])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rep = _Reply(p(out["rgba"]), p(out["gauge_mins"]), p(out["gauge_maxs"]), p(out["gauge_amps"]), p(out["c_hist"]),
+                     p(out["cB_hist"]), p(mm))
+        self._chk(self.lib.L.sp_render_named(self.h, C.byref(req), p(data), data.size, W, C.byref(rep)))
+        out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])
+        return out
+
+    def plan_creations(self):
+        n = C.c_int64()
+        self._chk(self.lib.L.sp_context_plan_creations(self.h, C.byref(n)))
+        return n.value
 
     def plan(self, fmt, n, windowc, block_norm, gain, rng, lut, channel_mode=False, waterfall=False):
         return Plan(self, fmt, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)

@@ -74,6 +74,7 @@ struct sp_context {
     std::vector<double> named_windowc;
     std::vector<uint8_t> named_lut;
     double named_block_norm = 0;
+    long long plans_created = 0; // sp_context_plan_creations: how many plans (table sets on the device) this context has built
     bool acc_dirty = false;      // a request failed between its two kernels: accumulators must be re-initialised
     int cell_toggle = 0;         // which of the two merged-cell buffers the next k_frames launch counts into
     // timing
@@ -536,7 +537,15 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
         delete p;
         return hip_fail(ctx, e, "plan table upload");
     }
+    ctx->plans_created++;
     *out = p;
+    return SP_OK;
+}
+
+extern "C" int sp_context_plan_creations(const sp_context *ctx, int64_t *count)
+{
+    if (!ctx || !count) return SP_ERR_INVALID_ARG;
+    *count = (int64_t)ctx->plans_created;
     return SP_OK;
 }
 
@@ -1010,6 +1019,17 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
 }
 
 // ------------------------------------------------------------------------------------------------- requests by name
+
+extern "C" int sp_named_resolve(const char *window, const char *cmap, const char **window_name, const char **cmap_key, int32_t *lut_len)
+{
+    // lookup(windows, name) || blackmanHarrisWindow (lib/spectroplot.js:241); lookup(cmaps, name) || cube1_cmap (:252-264)
+    if (window_name) *window_name = sphost::window_by_name(window ? window : "");
+    int ci = cmap_index(cmap ? cmap : "");
+    if (ci < 0) ci = 0;
+    if (cmap_key) *cmap_key = spcmap::kEntries[ci].key;
+    if (lut_len) *lut_len = spcmap::kEntries[ci].length;
+    return SP_OK;
+}
 
 extern "C" int sp_render_named(sp_context *ctx, const sp_named_request *nr, const uint8_t *bytes, size_t nbytes, int32_t width,
                                const sp_reply *reply)

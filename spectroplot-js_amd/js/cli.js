@@ -11,7 +11,7 @@
  * Output: binary PPM (P6, alpha dropped) or, with --out *.rgba, the raw RGBA bytes exactly as the reference's canvas holds them.
  */
 const fs = require('fs')
-const { renderSliced, parseFormat, parseFreqRate, cmapByName, windowByName, HipWorker } = require('./index.js')
+const { renderSliced, parseFormat, parseFreqRate, HipWorker } = require('./index.js')
 
 function main(argv) {
     const opt = { n: 512, width: 1024, window: 'blackmanHarris', cmap: 'cube1', gain: 6, range: 30, out: 'spectrogram.ppm' }
@@ -28,12 +28,11 @@ function main(argv) {
     const buffer = bytes.buffer.slice(bytes.byteOffset, bytes.byteOffset + bytes.byteLength)
     const format = opt.format || parseFormat(file)
     const n = parseInt(opt.n, 10), width = parseInt(opt.width, 10)
-    const cmap = cmapByName(opt.cmap)
-    const w = windowByName(opt.window)(n)
     const fr = parseFreqRate(file)
     const t0 = Date.now()
     return renderSliced({ buffer, format, n, width, workers: opt.workers ? parseInt(opt.workers, 10) : HipWorker.deviceCount(),
-        window: w, cmap, gain: parseFloat(opt.gain), range: parseFloat(opt.range), channelMode: !!opt.channelMode, waterfall: !!opt.waterfall })
+        // the option names travel as they are: the library resolves them as the reference's caller does (sp_render_named)
+        byName: true, window: String(opt.window), cmap: String(opt.cmap), gain: parseFloat(opt.gain), range: parseFloat(opt.range), channelMode: !!opt.channelMode, waterfall: !!opt.waterfall })
         .then(img => {
             if (opt.out.endsWith('.rgba')) {
                 fs.writeFileSync(opt.out, Buffer.from(img.data.buffer))

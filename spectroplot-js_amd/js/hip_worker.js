@@ -108,6 +108,41 @@ class HipWorker {
         })
     }
 
+    /**
+     * A request by option names instead of evaluated arrays - not part of the reference worker's wire contract (its messages carry the
+     * evaluated taper and colour map, lib/spectroplot.js:1213-1226), but what the reference's caller starts from: the library resolves
+     * `window` and `cmap` with the reference's lookup rules and defaults (lib/utils.js:25-40, lib/spectroplot.js:238-264), evaluates
+     * taper, block_norm and the end-forced colour map itself (:1113-1130) and keeps the device tables while names and numbers repeat.
+     * @param {{buffer: ArrayBuffer, format: string, window: string, cmap: string, n: number, width: number, gain?: number,
+     *          range?: number, channelMode?: boolean, waterfall?: boolean, offset?: number}} o
+     * @returns {Promise<object>} the reply, fields as in a worker reply; runs in the instance's request order
+     */
+    renderNamed(o) {
+        const run = () => new Promise((resolve, reject) => {
+            if (this._closed) { reject(new Error('worker has been terminated')); return }
+            let req
+            try { req = this._namedRequest(o) } catch (e) { reject(e); return }
+            addon().renderNamed(this._ctx, req, (err, r) => err ? reject(err) : resolve(this._wrap(o, r)))
+        })
+        const p = this._queue.then(run)
+        this._queue = p.then(() => null, () => null)
+        return p
+    }
+
+    _namedRequest(o) {
+        let buffer = o.buffer
+        if (ArrayBuffer.isView(buffer)) buffer = buffer.buffer.slice(buffer.byteOffset, buffer.byteOffset + buffer.byteLength)
+        return { format: String(o.format), window: String(o.window === undefined ? '' : o.window), cmap: String(o.cmap === undefined ? '' : o.cmap),
+            buffer, n: o.n, width: o.width, gain: o.gain === undefined ? 6 : o.gain, range: o.range === undefined ? 30 : o.range,
+            channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+    }
+
+    /** Synchronous form of renderNamed (tests). */
+    renderNamedSync(o) { return this._wrap(o, addon().renderNamedSync(this._ctx, this._namedRequest(o))) }
+
+    /** How many plans (table sets on the device) this worker's context has built so far. */
+    planCreations() { return addon().planCreations(this._ctx) }
+
     /** Synchronous render of one message (used by tests and by callers that drive the GPUs themselves). */
     renderSync(m) { return this._wrap(m, addon().renderSync(this._ctx, this._request(m))) }
 

@@ -11,18 +11,22 @@ const { HipWorker } = require('./hip_worker.js')
 function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node')) }
 
 /**
+ * With `byName: true`, `window` and `cmap` are option names (any spelling the reference's lookup accepts) and the slices go to the
+ * workers as named requests (HipWorker.renderNamed -> sp_render_named): taper, block_norm and the end-forced colour map are evaluated
+ * inside the library, once per worker while the names repeat.
  * @param {{buffer: ArrayBuffer, format: string, n: number, width: number, workers?: number, window?: string|{window, weight},
- *          cmap: number[][], gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean}} o
+ *          cmap: number[][]|string, gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean, byName?: boolean}} o
  * @returns {Promise<{data: Uint8ClampedArray, width, height, c_hist, cB_hist, dBfs_min, dBfs_max, sliceWidth, replies}>}
  */
 function renderSliced(o, pool) {
     const a = native()
     const workers = o.workers || Math.max(1, a.deviceCount())
     const n = o.n
-    const w = typeof o.window === 'object' && o.window ? o.window : a.window(o.window || 'blackmanHarris', n)
-    const block_norm = 1.0 / w.weight                                   // spectroplot.js:1116
-    const cmap = o.cmap.map(c => c.slice())
-    cmap[0] = [0, 0, 0]; cmap[cmap.length - 1] = [255, 255, 255]     // spectroplot.js:1129-1130
+    const byName = !!o.byName
+    const w = byName ? null : (typeof o.window === 'object' && o.window ? o.window : a.window(o.window || 'blackmanHarris', n))
+    const block_norm = byName ? 0 : 1.0 / w.weight                      // spectroplot.js:1116
+    const cmap = byName ? new Array(a.namedResolve(String(o.window), String(o.cmap)).lutLength) : o.cmap.map(c => c.slice())
+    if (!byName) { cmap[0] = [0, 0, 0]; cmap[cmap.length - 1] = [255, 255, 255] }   // spectroplot.js:1129-1130
     const gain = o.gain === undefined ? 6 : o.gain, range = o.range === undefined ? 30 : o.range
     const fmt = a.parseFormat(o.format)
     const width = o.width, sliceWidth = ~~(width / workers)             // spectroplot.js:1208
@@ -46,9 +50,14 @@ function renderSliced(o, pool) {
         // (without a device there is nothing to lock pages for: a caller-supplied pool of other workers gets a plain copy)
         const slice = a.deviceCount() > 0 ? a.allocBuffer(b1 - b0) : new ArrayBuffer(b1 - b0)
         new Uint8Array(slice).set(new Uint8Array(o.buffer, b0, b1 - b0))
+        const k = i % pool.length
+        if (byName) {
+            jobs.push(pool[k].renderNamed({ buffer: slice, format: o.format, window: o.window, cmap: o.cmap, n, width: sliceWidth,
+                offset: i * sliceWidth, gain, range, channelMode: !!o.channelMode, waterfall: !!o.waterfall }))
+            continue
+        }
         const message = { block_norm, gain, range, cmap, n, windowc: w.window, width: sliceWidth, offset: i * sliceWidth,
             buffer: slice, format: o.format, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
-        const k = i % pool.length
         jobs.push(new Promise((resolve, reject) => {
             pending[k].push({ resolve, reject })
             pool[k].postMessage(message, [message.buffer])

@@ -22,6 +22,11 @@
 //       runs sp_render on a libuv worker thread and calls cb(err, {rgba, gauge_mins, gauge_maxs, gauge_amps: ArrayBuffer,
 //       c_hist, cB_hist: Float64Array, dBfs_min, dBfs_max}) on the main thread
 //   renderSync(handle, req)                        -> the same reply object, synchronously
+//   renderNamed(handle, req, cb) / renderNamedSync(handle, req)   req = {format, window, cmap: strings, buffer, n, gain, range, width,
+//                                    channelMode, waterfall}: sp_render_named - the library resolves the names as the reference's caller
+//                                    does (lib/spectroplot.js:238-264, 1113-1146) and keeps the plan while they repeat
+//   namedResolve(window, cmap)                     -> {window, cmap, lutLength}: what the two option names resolve to (sp_named_resolve)
+//   planCreations(handle)                          -> how many plans this context has built (sp_context_plan_creations)
 #include <node_api.h>
 
 #include <cstdint>
@@ -177,6 +182,9 @@ struct Job {
     sp_request req{};
     std::vector<double> window;
     std::vector<uint8_t> lut;
+    // a request by option names (renderNamed): the library evaluates taper and colour map itself
+    bool named = false;
+    std::string nformat, nwindow, ncmap;
     const uint8_t *bytes = nullptr;
     size_t nbytes = 0;
     int32_t width = 0;
@@ -195,7 +203,18 @@ struct Job {
 
 void free_cb(napi_env, void *data, void *) { free(data); }
 
-bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
+std::string get_string(napi_env env, napi_value obj, const char *name)
+{
+    napi_value v, sv;
+    if (!get_named(env, obj, name, &v) || napi_coerce_to_string(env, v, &sv) != napi_ok) return "";
+    size_t len = 0;
+    napi_get_value_string_utf8(env, sv, nullptr, 0, &len);
+    std::string out(len, '\0');
+    napi_get_value_string_utf8(env, sv, &out[0], len + 1, &len);
+    return out;
+}
+
+bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j, bool named = false)
 {
     void *p = nullptr;
     if (napi_get_value_external(env, handle, &p) != napi_ok || !p) {
@@ -210,7 +229,14 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
     j->ctx = j->owner->c;
     napi_value v;
     int32_t i32 = 0;
-    get_named(env, req, "format", &v); napi_get_value_int32(env, v, &i32); j->req.format = i32;
+    j->named = named;
+    if (named) {
+        j->nformat = get_string(env, req, "format");
+        j->nwindow = get_string(env, req, "window");
+        j->ncmap = get_string(env, req, "cmap");
+    } else {
+        get_named(env, req, "format", &v); napi_get_value_int32(env, v, &i32); j->req.format = i32;
+    }
     get_named(env, req, "n", &v); napi_get_value_int32(env, v, &i32); j->req.n = i32;
     get_named(env, req, "width", &v); napi_get_value_int32(env, v, &i32); j->width = i32;
     j->req.channel_mode = get_bool(env, req, "channelMode");
@@ -228,6 +254,12 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j)
     }
     j->bytes = (const uint8_t *)data;
     j->nbytes = len;
+    if (named) {
+        int32_t lut_len = 0;
+        sp_named_resolve(j->nwindow.c_str(), j->ncmap.c_str(), nullptr, nullptr, &lut_len);   // sizes the reply's c_hist
+        j->req.lut_len = lut_len;
+        return true;
+    }
 
     napi_typedarray_type tt;
     napi_value ab;
@@ -272,7 +304,20 @@ void run_job(Job *j)
     sp_reply r{};
     r.rgba = j->rgba; r.gauge_mins = j->gmin; r.gauge_maxs = j->gmax; r.gauge_amps = j->gamp;
     r.c_hist = j->c_hist.data(); r.cb_hist = j->cb_hist.data(); r.dbfs_minmax = j->minmax;
-    j->status = sp_render(j->ctx, &j->req, j->bytes, j->nbytes, j->width, &r);
+    if (j->named) {
+        sp_named_request nr{};
+        nr.format = j->nformat.c_str();
+        nr.window = j->nwindow.c_str();
+        nr.cmap = j->ncmap.c_str();
+        nr.n = j->req.n;
+        nr.channel_mode = j->req.channel_mode;
+        nr.waterfall = j->req.waterfall;
+        nr.gain = j->req.gain;
+        nr.range = j->req.range;
+        j->status = sp_render_named(j->ctx, &nr, j->bytes, j->nbytes, j->width, &r);
+    } else {
+        j->status = sp_render(j->ctx, &j->req, j->bytes, j->nbytes, j->width, &r);
+    }
     if (j->status != SP_OK) j->error = sp_last_error(j->ctx);
 }
 
@@ -340,13 +385,20 @@ napi_value make_error(napi_env env, Job *j)
     return err;
 }
 
-napi_value RenderSync(napi_env env, napi_callback_info info)
+// An sp_context is one stream with one set of staging buffers: one render at a time.  HipWorker's promise queue already serialises
+// its requests; a second render on a handle whose first is still on a libuv thread is refused here rather than left to race.
+napi_value render_sync(napi_env env, napi_callback_info info, bool named)
 {
     size_t argc = 2;
     napi_value argv[2];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Job *j = new Job;
-    if (!parse_request(env, argv[0], argv[1], j)) { free_job(env, j); return nullptr; }
+    if (!parse_request(env, argv[0], argv[1], j, named)) { free_job(env, j); return nullptr; }
+    if (j->owner->inflight > 0) {
+        free_job(env, j);
+        napi_throw_error(env, nullptr, "a render is already in flight on this context");
+        return nullptr;
+    }
     j->owner->inflight++;
     run_job(j);
     j->owner->inflight--;
@@ -357,6 +409,8 @@ napi_value RenderSync(napi_env env, napi_callback_info info)
     free_job(env, j);
     return out;
 }
+napi_value RenderSync(napi_env env, napi_callback_info info) { return render_sync(env, info, false); }
+napi_value RenderNamedSync(napi_env env, napi_callback_info info) { return render_sync(env, info, true); }
 
 void exec_cb(napi_env, void *data) { run_job((Job *)data); }
 
@@ -380,24 +434,43 @@ void done_cb(napi_env env, napi_status, void *data)
     free_job(env, j);
 }
 
-napi_value Render(napi_env env, napi_callback_info info)
+napi_value render_async(napi_env env, napi_callback_info info, bool named)
 {
     size_t argc = 3;
     napi_value argv[3];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Job *j = new Job;
-    if (!parse_request(env, argv[0], argv[1], j)) { free_job(env, j); return nullptr; }
+    if (!parse_request(env, argv[0], argv[1], j, named)) { free_job(env, j); return nullptr; }
+    if (j->owner->inflight > 0) {
+        free_job(env, j);
+        napi_throw_error(env, nullptr, "a render is already in flight on this context");
+        return nullptr;
+    }
     napi_value buf, name;
-    napi_get_named_property(env, argv[1], "buffer", &buf);
-    napi_create_reference(env, buf, 1, &j->buf_ref);     // keep the input alive while the worker thread reads it
-    napi_create_reference(env, argv[2], 1, &j->cb_ref);
-    napi_create_reference(env, argv[0], 1, &j->ctx_ref);   // the handle (and with it the Ctx) stays reachable while the job runs
-    j->owner->inflight++;
-    napi_create_string_utf8(env, "spectroplot_hip.render", NAPI_AUTO_LENGTH, &name);
-    NAPI_OK(env, napi_create_async_work(env, nullptr, name, exec_cb, done_cb, j, &j->work));
-    NAPI_OK(env, napi_queue_async_work(env, j->work));
+    bool ok = napi_get_named_property(env, argv[1], "buffer", &buf) == napi_ok;
+    ok = ok && napi_create_reference(env, buf, 1, &j->buf_ref) == napi_ok;       // keep the input alive while the worker thread reads it
+    ok = ok && napi_create_reference(env, argv[2], 1, &j->cb_ref) == napi_ok;
+    ok = ok && napi_create_reference(env, argv[0], 1, &j->ctx_ref) == napi_ok;   // the handle (and with it the Ctx) stays reachable while the job runs
+    ok = ok && napi_create_string_utf8(env, "spectroplot_hip.render", NAPI_AUTO_LENGTH, &name) == napi_ok;
+    ok = ok && napi_create_async_work(env, nullptr, name, exec_cb, done_cb, j, &j->work) == napi_ok;
+    if (ok) {
+        // counted only once the work is certain to run: done_cb is what takes the count down again
+        j->owner->inflight++;
+        if (napi_queue_async_work(env, j->work) != napi_ok) {
+            j->owner->inflight--;
+            ok = false;
+        }
+    }
+    if (!ok) {
+        Ctx *owner = j->owner;
+        free_job(env, j);          // references, the work item, the buffers
+        ctx_release(owner);        // a context closed meanwhile is destroyed here if nothing else holds it
+        napi_throw_error(env, nullptr, "could not queue the render");
+    }
     return nullptr;
 }
+napi_value Render(napi_env env, napi_callback_info info) { return render_async(env, info, false); }
+napi_value RenderNamed(napi_env env, napi_callback_info info) { return render_async(env, info, true); }
 
 napi_value DeviceCount(napi_env env, napi_callback_info)
 {
@@ -575,6 +648,45 @@ napi_value CmapKeys(napi_env env, napi_callback_info)
     return out;
 }
 
+napi_value NamedResolve(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2], out, v, sv;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    std::string names[2];
+    for (int k = 0; k < 2; k++) {
+        size_t len = 0;
+        NAPI_OK(env, napi_coerce_to_string(env, argv[k], &sv));
+        napi_get_value_string_utf8(env, sv, nullptr, 0, &len);
+        names[k].assign(len, '\0');
+        napi_get_value_string_utf8(env, sv, &names[k][0], len + 1, &len);
+    }
+    const char *wname = "", *ckey = "";
+    int32_t lut_len = 0;
+    sp_named_resolve(names[0].c_str(), names[1].c_str(), &wname, &ckey, &lut_len);
+    NAPI_OK(env, napi_create_object(env, &out));
+    napi_create_string_utf8(env, wname, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "window", v);
+    napi_create_string_utf8(env, ckey, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "cmap", v);
+    napi_create_int32(env, lut_len, &v); napi_set_named_property(env, out, "lutLength", v);
+    return out;
+}
+
+napi_value PlanCreations(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1], v;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p || !((Ctx *)p)->c) {
+        napi_throw_type_error(env, nullptr, "context handle expected");
+        return nullptr;
+    }
+    int64_t n = 0;
+    sp_context_plan_creations(((Ctx *)p)->c, &n);
+    NAPI_OK(env, napi_create_int64(env, n, &v));
+    return v;
+}
+
 napi_value CreateContext(napi_env env, napi_callback_info info)
 {
     size_t argc = 1;
@@ -612,6 +724,10 @@ napi_value Init(napi_env env, napi_value exports)
         {"cmapKeys", nullptr, CmapKeys, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"renderSync", nullptr, RenderSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"renderNamed", nullptr, RenderNamed, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"renderNamedSync", nullptr, RenderNamedSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"namedResolve", nullptr, NamedResolve, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"planCreations", nullptr, PlanCreations, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     napi_value v;

@@ -103,3 +103,19 @@ def test_fails_loudly_without_device(pkg):
     assert ei.value.status == -5
     with pytest.raises(pkg.SpectroplotError):
         pkg.HipWorker(0)
+
+
+def test_option_names_resolve_as_the_reference_resolves_them(pkg):
+    """sp_named_resolve (no device needed) against the keys the reference's own lookup() was asked for (tests/golden/parse.json)."""
+    import json
+    import os
+    named_resolve = pkg.binding.named_resolve
+    parse = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parse.json")))
+    for e in parse["lookups"]:
+        want = (e["hit"] or "blackmanHarrisWindow")[:-len("Window")]            # lookup(...) || blackmanHarrisWindow
+        assert named_resolve(e["key"], "cube1")[0] == want, e
+    for e in parse["clookups"]:
+        key, length = named_resolve("hann", e["key"])[1:]
+        assert key == (e["hit"] or "cube1_cmap"), e                             # lookup(...) || cube1_cmap
+        assert length == (64 if key == "parabola_cmap" else 256)
+    assert named_resolve("", "")[:2] == ("blackmanHarris", "cube1_cmap")

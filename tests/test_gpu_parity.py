@@ -572,3 +572,62 @@ def test_full_size_repeatable(pkg, ctx):
             assert np.array_equal(a, b)
     ctx.free(d_in)
     plan.close()
+
+
+def test_requests_by_name_match_the_golden_vectors_and_reuse_their_plan(pkg, golden):
+    """sp_render_named: the request given as option names, resolved inside the library with the reference's lookup rules and defaults
+    (lib/utils.js:25-40, lib/spectroplot.js:238-264, 1113-1146; the keys are the ones tests/golden/parse.json recorded from the reference).
+    Every golden worker case whose taper and colour map the reference ships is rendered by names only and compared with the real
+    worker's reply; spellings that resolve to the same table entry give the same reply; a repeated request builds no new plan."""
+    import json
+    import os
+    parse = json.load(open(os.path.join(goldenlib.GDIR, "parse.json")))
+    win_hits = {e["key"]: e["hit"] for e in parse["lookups"]}
+    cmap_hits = {e["key"]: e["hit"] for e in parse["clookups"]}
+    ctx = pkg.Context(0)
+    bad, ran = [], 0
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "reply" not in e or c["cmap"].startswith("custom:") or not c["force_ends"] or c["width"] == 0:
+            continue
+        # the table keys themselves: a bare 'blackman' is a prefix of the sorted table's 'blackmanHarrisWindow' too and resolves to that one
+        r = ctx.render_named(c["format"], golden.input(c), c["n"], c["window"] + "Window", c["cmap"] + "_cmap", c["gain"], c["range"],
+                             c["width"], c["channelMode"], c["waterfall"])
+        bad += goldenlib.check_reply(r, e["reply"], c["name"] + " by name: ")
+        ran += 1
+    assert ran > 60 and not bad, (ran, bad[:20])
+
+    # spellings: every recorded key against the array path with what the reference resolved it to
+    c = golden.cases["cfg2_scaled"]
+    data = golden.input(c)
+
+    def by_arrays(window_hit, cmap_hit):
+        wname = (window_hit or "blackmanHarrisWindow")[:-len("Window")]
+        win, weight = pyoracle.window(wname, c["n"])
+        lut = golden.lut((cmap_hit or "cube1_cmap")[:-len("_cmap")], force_ends=True)
+        return ctx.render(c["format"], data, c["n"], win, 1.0 / weight, c["gain"], c["range"], lut, c["width"])
+
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k]) for k in ("rgba", "gauge_mins", "gauge_maxs", "gauge_amps", "c_hist", "cB_hist")) \
+            and a["dBfs_min"] == b["dBfs_min"] and a["dBfs_max"] == b["dBfs_max"]
+
+    win_hits["blackman"] = "blackmanHarrisWindow"   # first prefix hit in the reference's (sorted) key order
+    for key in ("hann", "Hann", "black", "blackman", "nosuch", "ha", "b", "rect", "HANNWINDOW"):
+        got = ctx.render_named(c["format"], data, c["n"], key, "viridis", c["gain"], c["range"], c["width"])
+        assert same(got, by_arrays(win_hits[key], "viridis_cmap")), "window key %r" % key
+    for key in ("v", "VIRIDIS", "nosuch", "p", "pl", "h", "gist", "inferno_cmap", "cube1"):
+        got = ctx.render_named(c["format"], data, c["n"], "blackmanHarris", key, c["gain"], c["range"], c["width"])
+        assert len(got["c_hist"]) == len(golden.lut((cmap_hits[key] or "cube1_cmap")[:-5])), key
+        assert same(got, by_arrays("blackmanHarrisWindow", cmap_hits[key])), "cmap key %r" % key
+
+    # the plan stays while names and numbers repeat; a changed name or number builds one new plan
+    ctx.render_named("cf32", data, c["n"], "hann", "v", 6.0, 30.0, c["width"])
+    n0 = ctx.plan_creations()
+    for _ in range(3):
+        ctx.render_named("cf32", data, c["n"], "hann", "v", 6.0, 30.0, c["width"])
+    assert ctx.plan_creations() == n0
+    ctx.render_named("cf32", data, c["n"], "hann", "v", 7.0, 30.0, c["width"])
+    assert ctx.plan_creations() == n0 + 1
+    ctx.render_named("cf32", data, c["n"], "Hann", "v", 7.0, 30.0, c["width"])       # another spelling: re-resolved, one more plan at most
+    assert ctx.plan_creations() <= n0 + 2
+    ctx.close()

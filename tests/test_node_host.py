@@ -58,3 +58,11 @@ def test_hip_worker_reproduces_golden_vectors():
     out = _node("check_hip_worker.js")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bit-for-bit" in out.stdout
+
+
+@pytest.mark.gpu
+def test_named_requests_and_the_command_line_renderer():
+    """HipWorker.renderNamed (sp_render_named through N-API) on the golden vectors, plan reuse, and js/cli.js on a capture file."""
+    out = _node("check_named.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "named requests ok" in out.stdout
