@@ -100,6 +100,64 @@ def e2e_dropin():
         return {"failed": repr(e)}
 
 
+PROFILE_TAG = "r03"   # profiles/<tag>_<config>_{traffic,valu}.json: committed rocprofv3 --pmc summaries of this same command
+
+
+def rocprof_kernel_us(argv_config):
+    """Average duration of the frame-loop kernel by rocprofv3 --kernel-trace --stats over a short child run of this same command (the
+    figure the committed profiles/<tag>_<config>_kernel_stats.csv holds).  Started before this process touches the GPU.  None when
+    rocprofv3 is not there or anything about the child run fails: the roofline then uses the un-corrected event-pair time."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    d = tempfile.mkdtemp(prefix="sp_kt_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "400", "--warmup", "100", "--no-cpu-baseline", "--no-e2e", "--no-rocprof"] + argv_config
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        best = None
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if any(k in row["Name"] for k in ("k_frames", "k_lds_r16", "k_scratch_radix2")):
+                    t = float(row["TotalDurationNs"])
+                    if best is None or t > best[0]:
+                        best = (t, float(row["AverageNs"]) / 1e3, int(row["Calls"]), row["Name"].split("(")[0])
+        return None if best is None else {"avg_us": best[1], "calls": best[2], "kernel": best[3]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def valu_roofline(config, kernel_us, frames):
+    """The resource that binds the frame loop in fact: VALU issue.  Counted wave-instructions per launch (rocprofv3
+    --pmc, committed under profiles/) times the measured issue cost of their class with two waves per SIMD (profiles/r02_op_cost.txt),
+    over the chip's 1024 SIMDs at 2.4 GHz: the time the launch would take if no SIMD ever waited."""
+    f = os.path.join(ROOT, "profiles", "%s_%s_valu.json" % (PROFILE_TAG, config))
+    if not os.path.exists(f):
+        return None
+    c = json.load(open(f))["counters"]
+    if not c.get("SQ_INSTS_VALU"):
+        return None
+    g = lambda k: c.get(k) or 0.0  # noqa: E731
+    f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
+    cvt, trans, i32 = g("SQ_INSTS_VALU_CVT"), g("SQ_INSTS_VALU_TRANS_F32"), g("SQ_INSTS_VALU_INT32") + g("SQ_INSTS_VALU_INT64")
+    f32 = g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
+    other = max(g("SQ_INSTS_VALU") - f64 - cvt - trans - i32 - f32, 0.0)
+    cost = {"f64": 4.7, "cvt": 4.6, "trans_f32": 8.8, "int": 2.5, "f32": 3.0, "other": 4.5}   # cycles per wave-instruction per SIMD
+    cycles = f64 * cost["f64"] + cvt * cost["cvt"] + trans * cost["trans_f32"] + i32 * cost["int"] + f32 * cost["f32"] + other * cost["other"]
+    floor_us = cycles / 1024.0 / 2400.0
+    return {"bound": "f64 VALU issue", "f64_wave_insts": f64, "f64_wave_insts_per_frame_wave": f64 / max(frames, 1), "fused_f64_insts": g("SQ_INSTS_VALU_FMA_F64"),
+            "valu_wave_insts": g("SQ_INSTS_VALU"), "cycles_per_inst": cost["f64"], "class_costs": cost,
+            "class_counts": {"f64": f64, "cvt": cvt, "trans_f32": trans, "int": i32, "f32": f32, "other": other},
+            "floor_us": floor_us, "kernel_us": kernel_us, "frac": floor_us / kernel_us if kernel_us else None,
+            "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r02_op_cost.txt" % (PROFILE_TAG, config)}
+
+
 def launch_ranks(argv, gpus):
     """`python bench.py --gpus N` started plainly: one child rank per GPU through torch.distributed.run, before this process has
     touched the GPU; the children's output (rank 0 prints the JSON line) passes through."""
@@ -122,6 +180,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(default when N > 1) also time the RCCL gather of the RGBA strips to rank 0")
     ap.add_argument("--no-gather", action="store_true", help="skip the strip gather")
     ap.add_argument("--no-e2e", action="store_true", help="skip the Node drop-in leg")
+    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run that times the dominant kernel (N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--oversubscribe", action="store_true", help="diagnostic: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--force-dist", action="store_true",
@@ -135,6 +194,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+
+    # dominant kernel's duration as rocprofv3 reports it: a short child run of this command, before this process touches the GPU
+    prof = None
+    if args.gpus == 1 and not args.no_rocprof and "WORLD_SIZE" not in os.environ:
+        prof = rocprof_kernel_us(["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else []))
 
     import numpy as np
     import torch
@@ -290,16 +354,45 @@ def main():
     # An event pair adds the dispatch latency of the packet it brackets (measured here on a one-wavefront no-op kernel);
     # rocprofv3's kernel duration (profiles/) does not contain it.  The roofline uses the kernel's own duration.
     event_overhead_ms = ctx.event_pair_overhead_ms()
-    kernel_ms = max(kernel_ms_events - event_overhead_ms, 0.5 * kernel_ms_events)
+    # roofline: the kernel's duration as rocprofv3 --kernel-trace reports it (the child run above); without rocprofv3, the event-pair
+    # time as measured, un-corrected (it contains the dispatch latency: a lower bound on the fraction)
+    kernel_ms = prof["avg_us"] * 1e-3 if prof else kernel_ms_events
 
-    gather_ms = None
+    gather_ms = place_ms = merged_ok = None
     if dist is not None and not args.no_gather:
-        strips = [torch.empty_like(rgba) for _ in range(world)] if rank == 0 else None
+        # the caller's putImageData of every slice (lib/spectroplot.js:1241-1244), HBM to HBM: the strips are gathered into ONE device
+        # buffer on rank 0 (rank order) and placed in the merged image by sp_place_strips; both steps are timed, outside the timed region
+        per = rgba.numel()
+        allstrips = torch.empty(world * per, dtype=torch.uint8, device=dev) if rank == 0 else None
+        bufs = [allstrips[r * per:(r + 1) * per] for r in range(world)] if rank == 0 else None
         sync()
         g0 = time.perf_counter()
-        dist.gather(rgba, strips, dst=0)
+        dist.gather(rgba, bufs, dst=0)
         sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            image = torch.zeros(world * per, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            ctx.place_strips(image.data_ptr(), allstrips.data_ptr(), world, n, world * W, W, args.waterfall)
+            torch.cuda.synchronize()
+            place_ms = (time.perf_counter() - p0) * 1e3
+            # check: rank 0 renders every slice itself (the generator is seekable) and composes the image with torch indexing
+            want = torch.empty_like(image)
+            wv = want.view(world * W, n, 4) if args.waterfall else want.view(n, world * W, 4)
+            one = torch.empty_like(rgba)
+            tmp_in = torch.empty_like(d_in)
+            for r in range(world):
+                ctx.synth_trinoise(tmp_in.data_ptr(), fmt, r * S, S, GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])
+                plan.execute(tmp_in.data_ptr(), S * sw, W, one.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                             records[0].data_ptr(), records[0].data_ptr() + 8 * L, records[0].data_ptr() + 8 * (L + 1000))
+                torch.cuda.synchronize()
+                if args.waterfall:
+                    wv[world * W - W - r * W:world * W - r * W] = one.view(W, n, 4)
+                else:
+                    wv[:, r * W:(r + 1) * W] = one.view(n, W, 4)
+            merged_ok = bool(torch.equal(image, want))
+            del want, one, tmp_in, image, allstrips
 
     stride_eff = min((S - n) / (W - 1), n)
     bytes_per_frame = sw * stride_eff + 4 * n + 3                 # unique input bytes + RGBA + 3 gauge bytes
@@ -307,10 +400,13 @@ def main():
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     frames_per_s = world * W * args.steps / dt
 
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % args.config)
-    if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed)
-        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+    traffic, traffic_source = None, None
+    for tag in (PROFILE_TAG, "r02"):
+        tfile = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (tag, args.config))
+        if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed, not live)
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s_%s_traffic.json (committed rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command; not measured in this run)" % (tag, args.config)
+            break
 
     if rank == 0:
         out = {
@@ -329,22 +425,31 @@ def main():
             "msamples_per_s": frames_per_s * stride_eff / 1e6,
             "kernel": plan.kernel_name(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "kernel_ms_event_pair": kernel_ms_events, "event_pair_overhead_ms": event_overhead_ms,
+                         "traffic_source": traffic_source,
+                         "kernel_ms": kernel_ms,
+                         "kernel_ms_source": ("rocprofv3 --kernel-trace --stats, child run of this command: average of %d launches of %s"
+                                              % (prof["calls"], prof["kernel"])) if prof else "HIP event pair around the kernel, un-corrected",
+                         "kernel_ms_event_pair": kernel_ms_events, "event_pair_overhead_ms": event_overhead_ms,
+                         "kernel_ms_event_pair_minus_overhead": max(kernel_ms_events - event_overhead_ms, 0.0),
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
                          "frac_of_copy_ceiling_6290": achieved / 6290.0},
+            "roofline_valu": valu_roofline(args.config, kernel_ms * 1e3, W) if world == 1 else None,
             "checks": {"c_hist_sum": hsum, "expected": world * W * n},
             "renders_per_collective": M if dist is not None else None,
         }
         if gather_ms is not None:
             out["rgba_gather_ms"] = gather_ms
             out["rgba_gather_GBps"] = (world - 1) * rgba.numel() / (gather_ms * 1e-3) / 1e9
+            out["rgba_place_ms"] = place_ms
+            out["rgba_place_GBps"] = 2 * world * rgba.numel() / (place_ms * 1e-3) / 1e9 if place_ms else None
+            out["checks"]["merged_image_equals_single_slice_renders"] = merged_ok
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fmt, n, window)
         if world == 1 and not args.no_e2e and args.config == "cfg2":
             out["e2e"] = e2e_dropin()
         print(json.dumps(out))
-        if hsum != world * W * n:
-            print("bench.py: colour histogram total %d != %d pixels" % (hsum, world * W * n), file=sys.stderr)
+        if hsum != world * W * n or merged_ok is False:
+            print("bench.py: colour histogram total %d (expected %d pixels), merged image check %r" % (hsum, world * W * n, merged_ok), file=sys.stderr)
             plan.close()
             sys.exit(1)
     plan.close()

@@ -18,6 +18,8 @@
  *   sp_plan_create           lib/worker.js:30-62        per-request constants + the cached FFT object
  *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
  *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
+ *   sp_merge_replies         lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
+ *   sp_place_strips          lib/spectroplot.js:1241-1244   the caller's putImageData of every slice's strip, on the device
  *   sp_synth_*               (none)                     device-side synthetic I/Q for benchmarks
  *
  * The request fields are the reference message's (lib/spectroplot.js:1213-1226):
@@ -186,6 +188,15 @@ int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t w
  */
 int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int32_t lut_len, uint64_t *d_c_hist, uint64_t *d_cb_hist,
                      double *d_dbfs_minmax);
+/*
+ * The caller's strip placement (lib/spectroplot.js:1241-1244: putImageData(strip, offset, 0), or (0, width - sliceWidth - offset) for the
+ * waterfall layout) on device-resident strips: `count` strips of slice_width frames each, laid end to end at d_strips (what a gather of
+ * the ranks' strips delivers, rank order), are placed in the merged image at d_image (n rows x width columns of RGBA, or width rows x n
+ * columns for the waterfall layout).  Columns / rows beyond count * slice_width are left as they are (the caller's canvas keeps them
+ * blank: clear the image first).  Asynchronous on the context's stream.
+ */
+int sp_place_strips(sp_context *ctx, uint8_t *d_image, const uint8_t *d_strips, int32_t count, int32_t n, int32_t width,
+                    int32_t slice_width, int32_t waterfall);
 /* Name of the kernel variant sp_plan_execute launches ("frames", "lds_r16", "scratch_radix2"). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
 /* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16, 3 frames. */

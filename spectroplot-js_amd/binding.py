@@ -107,6 +107,7 @@ class Library:
         L.sp_context_enable_timing.argtypes = [vp, i32]
         L.sp_merge_replies.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.sp_place_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
 
     @classmethod
     def get(cls):
@@ -214,6 +215,11 @@ class Context:
         """Device-side merge of `count` slice records [c_hist | cB_hist | dBfs_min, dBfs_max] (the caller's merge, spectroplot.js:1229-1238)."""
         self._chk(self.lib.L.sp_merge_replies(self.h, C.c_void_p(d_records), int(count), int(lut_len), C.c_void_p(d_c_hist or None),
                                               C.c_void_p(d_cb_hist or None), C.c_void_p(d_minmax or None)))
+
+    def place_strips(self, d_image, d_strips, count, n, width, slice_width, waterfall=False):
+        """Device-side putImageData of `count` gathered strips (laid end to end at d_strips) into the merged image (spectroplot.js:1241-1244)."""
+        self._chk(self.lib.L.sp_place_strips(self.h, C.c_void_p(d_image), C.c_void_p(d_strips), int(count), int(n), int(width),
+                                             int(slice_width), int(bool(waterfall))))
 
     def event_pair_overhead_ms(self):
         ms = C.c_float()

@@ -869,6 +869,51 @@ extern "C" int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t 
     return SP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------- strip placement
+
+// putImageData(strip, offset, 0) for every gathered strip at once (lib/spectroplot.js:1241-1244): strip r of `count`, laid end to end in
+// `strips` as an all-gather / gather delivers them, goes to columns [r * slice_width, (r + 1) * slice_width) of the n x width image
+// (spectrogram), or to rows [width - slice_width - r * slice_width, ...) of the width x n image (waterfall: row bands in reverse order).
+// One thread moves one V (16 bytes = 4 pixels where the widths allow, else one pixel); reads and writes are whole row pieces.
+template <typename V>
+__global__ void k_place_strips(uint8_t *__restrict__ image, const uint8_t *__restrict__ strips, int count, int n, int width, int slice_width,
+                               int waterfall)
+{
+    constexpr int PX = (int)sizeof(V) / 4;
+    const size_t units_per_strip = (size_t)slice_width * (size_t)n / PX;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= units_per_strip * (size_t)count) return;
+    const int r = (int)(i / units_per_strip);
+    const size_t u = i % units_per_strip;
+    size_t dst;
+    if (waterfall) {
+        dst = ((size_t)(width - slice_width - r * slice_width) * (size_t)n) / PX + u;        // one contiguous band of rows
+    } else {
+        const size_t row_units = (size_t)slice_width / PX;
+        const size_t y = u / row_units, x = u % row_units;
+        dst = (y * (size_t)width + (size_t)r * (size_t)slice_width) / PX + x;
+    }
+    ((V *)image)[dst] = ((const V *)strips)[i];
+}
+
+extern "C" int sp_place_strips(sp_context *ctx, uint8_t *d_image, const uint8_t *d_strips, int32_t count, int32_t n, int32_t width,
+                               int32_t slice_width, int32_t waterfall)
+{
+    if (!ctx || !d_image || !d_strips || count < 1 || n < 1 || width < 1 || slice_width < 0) return SP_ERR_INVALID_ARG;
+    if ((int64_t)count * slice_width > width) return fail(ctx, SP_ERR_INVALID_ARG, "strips do not fit the image");
+    if (slice_width == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const bool wide = (slice_width & 3) == 0 && (width & 3) == 0 && (((uintptr_t)d_image | (uintptr_t)d_strips) & 15) == 0
+                      && (!waterfall || (n & 3) == 0);
+    const size_t units = (size_t)slice_width * (size_t)n * (size_t)count / (wide ? 4 : 1);
+    const size_t blocks = (units + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ctx, SP_ERR_UNSUPPORTED, "image too large for one placement launch");
+    if (wide) hipLaunchKernelGGL(k_place_strips<uint4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_image, d_strips, count, n, width, slice_width, waterfall);
+    else hipLaunchKernelGGL(k_place_strips<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_image, d_strips, count, n, width, slice_width, waterfall);
+    SP_HIP(ctx, hipGetLastError());
+    return SP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- host-buffer render
 
 static bool same_request(const sp_plan *p, const sp_request *r)

@@ -27,7 +27,9 @@ def slice_width(width, world):
 
 
 def merge_side_outputs(c_hist, cb_hist, dbfs_min, dbfs_max, device=None, group=None):
-    """All-reduces the per-slice side outputs in place of the caller's merge loop; returns (c_hist, cB_hist, min, max)."""
+    """All-reduces the per-slice side outputs in place of the caller's merge loop; returns (c_hist, cB_hist, min, max).
+    Host-side replies (the worker-message path): the counts travel through `device` when one is given (required for the nccl backend),
+    else as CPU tensors (gloo).  The HBM-resident path is render_sharded_device below."""
     dev = device or "cpu"
     h = torch.cat([torch.as_tensor(np.asarray(c_hist, dtype=np.int64)), torch.as_tensor(np.asarray(cb_hist, dtype=np.int64))]).to(dev)
     mm = torch.tensor([-float(dbfs_min), float(dbfs_max)], dtype=torch.float64, device=dev)   # (-min, max): one MAX serves both
@@ -86,3 +88,50 @@ def render_sharded(render_fn, data, fmt, n, width, windowc, weight, cmap, gain, 
     img = gather_strips(strip, n, width, waterfall, dst=dst, group=group)
     return {"data": None if img is None else img.cpu().numpy(), "c_hist": c_hist, "cB_hist": cb_hist, "dBfs_min": dmin,
             "dBfs_max": dmax, "slice_width": slw, "reply": reply}
+
+
+def render_sharded_device(plan, d_slice, width, waterfall=False, dst=0, group=None, want_image=True):
+    """One capture over all ranks, operands resident in HBM from the raw bytes to the merged image.
+
+    `plan` is this rank's binding.Plan (same request on every rank), `d_slice` a uint8 CUDA tensor holding this rank's slice of the
+    capture (bytes [my_slice(...)) of it), `width` the frames of the WHOLE image.  Rank r renders `slice_width(width, world)` frames with
+    sp_plan_execute into a device strip and a device record [c_hist | cB_hist | dBfs range]; the records are all-gathered and reduced on
+    the device (sp_merge_replies: the caller's merge, lib/spectroplot.js:1229-1238); the strips are gathered to `dst` and placed on the
+    device (sp_place_strips: putImageData, :1241-1244).  This function never copies a strip, histogram or gauge to host memory: the
+    collectives are handed device tensors (nccl = RCCL moves them over xGMI; gloo, used by the tests whose ranks share one GPU, stages
+    them through the host inside the collective: its transport, not this path).
+
+    Returns device tensors: {"image": uint8 [4 * width * n] on dst (None elsewhere), "record": int64 [L + 1000 + 2] merged side outputs
+    (every rank), "strip", "gauges": uint8 [3 * slice_width] (this rank's gauge_mins | gauge_maxs | gauge_amps), "slice_width"}."""
+    ctx, n, L = plan.ctx, plan.n, plan.lut_len
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = d_slice.device
+    slw = slice_width(width, world)
+    P = L + binding.SP_CB_HIST_SIZE + 2
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)                 # the library's kernels join torch's stream: collectives queue behind them
+    strip = torch.empty(max(4 * slw * n, 16), dtype=torch.uint8, device=dev)
+    gauges = torch.empty(max(3 * slw, 16), dtype=torch.uint8, device=dev)
+    record = torch.zeros(P, dtype=torch.int64, device=dev)
+    p = record.data_ptr()
+    plan.execute(d_slice.data_ptr(), d_slice.numel(), slw, strip.data_ptr(), gauges.data_ptr(), gauges.data_ptr() + slw,
+                 gauges.data_ptr() + 2 * slw, p, p + 8 * L, p + 8 * (L + binding.SP_CB_HIST_SIZE))
+    gathered = torch.empty(world * P, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, record, group=group)
+    merged = torch.empty(P, dtype=torch.int64, device=dev)
+    m = merged.data_ptr()
+    ctx.merge_replies(gathered.data_ptr(), world, L, m, m + 8 * L, m + 8 * (L + binding.SP_CB_HIST_SIZE))
+    image = None
+    if want_image:
+        per = 4 * slw * n
+        bufs = None
+        if rank == dst:
+            allstrips = torch.empty(max(world * per, 16), dtype=torch.uint8, device=dev)
+            bufs = [allstrips[r * per:(r + 1) * per] for r in range(world)]          # views: the gather fills one buffer, rank order
+        dist.gather(strip[:per], bufs, dst=dst, group=group)
+        if rank == dst:
+            image = torch.zeros(4 * width * n, dtype=torch.uint8, device=dev)        # un-rendered columns stay blank, as on the canvas
+            if per:
+                ctx.place_strips(image.data_ptr(), allstrips.data_ptr(), world, n, width, slw, waterfall)
+    stream.synchronize()
+    return {"image": image, "record": merged, "strip": strip[:4 * slw * n], "gauges": gauges[:3 * slw], "slice_width": slw}

@@ -44,6 +44,11 @@ def test_single_gpu_line_has_roofline_and_checks():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    # the kernel time is rocprofv3's own figure (a child run of the same command), never an event time with something subtracted
+    assert r["kernel_ms_source"].startswith("rocprofv3 --kernel-trace") and 0.5 * r["kernel_ms_event_pair"] < r["kernel_ms"] <= r["kernel_ms_event_pair"]
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    v = d["roofline_valu"]
+    assert v is None or (v["bound"] == "f64 VALU issue" and v["fused_f64_insts"] == 0 and 0.0 < v["frac"] < 1.0)
 
 
 @pytest.mark.parametrize("merge_every", [1, 3])
@@ -56,7 +61,7 @@ def test_two_ranks_on_one_gpu_merge_every_render(merge_every):
 
 def test_one_rank_rccl_group_runs_the_collectives():
     """The N > 1 path's collectives through the nccl backend (RCCL) with a one-rank group: all the box has is one GPU."""
-    d = run_bench("--force-dist", "--steps", "40", "--warmup", "5", "--merge-every", "16", "--no-cpu-baseline", "--no-e2e")
+    d = run_bench("--force-dist", "--steps", "40", "--warmup", "5", "--merge-every", "16", "--no-cpu-baseline", "--no-e2e", "--no-rocprof")
     assert d["n_gpus"] == 1 and d["renders_per_collective"] == 16
     assert d["checks"]["c_hist_sum"] == d["checks"]["expected"] == 16384 * 1024
     assert d["rgba_gather_ms"] > 0

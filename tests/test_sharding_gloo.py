@@ -91,3 +91,74 @@ def test_ranks_with_the_product_renderer_reproduce_reference_merge(tmp_path, gol
     mp.spawn(_rank_main, args=(world, _free_port(), names, str(tmp_path), "hip"), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("rank%d" % r)).read() == "ok", r
+
+
+def _device_rank_main(rank, world, port, case_names, out_dir, backend):
+    """Every rank: its slice of the capture on the device -> sharding.render_sharded_device -> merged record / image on the device."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import goldenlib
+    from __graft_entry__ import load_package
+    from oracle import pyoracle
+    pkg = load_package()
+    from spectroplot_js_amd import sharding
+    g = goldenlib.Golden()
+    ctx = pkg.Context(dev.index)
+    ok = True
+    for name in case_names:
+        c, e = g.cases[name], g.expected[name]
+        data = g.input(c)
+        win, weight = pyoracle.window(c["window"], c["n"])
+        lut = g.lut(c, force_ends=c["force_ends"])
+        plan = ctx.plan(c["format"], c["n"], win, 1.0 / weight, c["gain"], c["range"], lut, c["channelMode"], c["waterfall"])
+        b0, b1 = sharding.my_slice(data.size, pkg.parse_format(c["format"])[1], rank, world)
+        d_slice = torch.from_numpy(np.ascontiguousarray(data[b0:b1])).to(dev)
+        m = sharding.render_sharded_device(plan, d_slice, c["width"], waterfall=c["waterfall"])
+        L = len(lut)
+        rec = m["record"].cpu().numpy()
+        ok &= [int(v) for v in rec[:L]] == e["merged"]["c_hist"]
+        mm = rec[L + 1000:].view(np.float64)
+        # the caller starts its merge from dBfs_min = 0, dBfs_max = -200 (spectroplot.js:1125-1126); every slice reply is already clamped so
+        ok &= goldenlib.same_f64(float(mm[0]), e["merged"]["dBfs_min"]) and goldenlib.same_f64(float(mm[1]), e["merged"]["dBfs_max"])
+        ok &= m["slice_width"] == e["merged"]["slice_width"]
+        ok &= goldenlib.sha256(m["strip"].cpu().numpy()) == e["slices"][rank]["rgba_sha256"]
+        slw = m["slice_width"]
+        gz = m["gauges"].cpu().numpy()
+        for k, key in enumerate(("gauge_mins", "gauge_maxs", "gauge_amps")):
+            ok &= gz[k * slw:(k + 1) * slw].tobytes().hex() == e["slices"][rank][key]
+        if rank == 0:
+            ok &= m["image"].is_cuda and goldenlib.sha256(m["image"].cpu().numpy()) == e["merged"]["rgba_sha256"]
+        else:
+            ok &= m["image"] is None
+        plan.close()
+    ctx.close()
+    with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+        f.write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (8, "gloo"), (1, "nccl")])
+def test_device_resident_sharded_render_reproduces_reference_merge(tmp_path, golden, world, backend):
+    """sharding.render_sharded_device: slice bytes in HBM -> sp_plan_execute -> records all-gathered and merged on the device
+    (sp_merge_replies) -> strips gathered and placed on the device (sp_place_strips), against the reference's merged vectors for `world`
+    workers (cfg4_scaled_8slices among them).  2 and 8 ranks share this box's one GPU (gloo carries the collectives); the one-rank nccl
+    group runs the same code with RCCL moving device tensors."""
+    names = [n for n, c in golden.cases.items() if c.get("slices") == world]
+    if world == 1:
+        names = [n for n, c in golden.cases.items() if c.get("slices") == 1][:4] or []
+    assert names, "no golden case with %d slices" % world
+    mp.spawn(_device_rank_main, args=(world, _free_port(), names, str(tmp_path), backend), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("rank%d" % r)).read() == "ok", r

@@ -29,6 +29,23 @@ print(json.dumps({"config": sys.argv[2], "kernel": name,
   "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0}, indent=1))
 PY
   mkdir -p $ROOT/profiles && cp $OUT/${TAG}_${C}_traffic.json $ROOT/profiles/${TAG}_${C}_traffic.json
+  # the instruction mix bench.py's roofline_valu object is computed from (counted wave-instructions per launch)
+  python3 - "$OUT/${TAG}_${C}_pmc_summary.txt" "$C" > $OUT/${TAG}_${C}_valu.json <<'PY'
+import json, re, sys
+txt = open(sys.argv[1]).read()
+blk = [b for b in txt.split("== ") if "k_frames" in b or "k_lds_r16" in b or "k_scratch" in b]
+blk = max(blk, key=lambda b: float(re.search(r"SQ_WAVE_CYCLES\s+n=\s*\d+\s+mean=\s*([\d.]+)", b).group(1)) if "SQ_WAVE_CYCLES" in b else 0)
+def g(k):
+    m = re.search(k + r"\s+n=\s*\d+\s+mean=\s*([\d.]+)", blk)
+    return float(m.group(1)) if m else None
+keys = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_TRANS_F32",
+        "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_SALU",
+        "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+print(json.dumps({"config": sys.argv[2], "kernel": blk.splitlines()[0],
+  "source": "rocprofv3 --pmc (tools/prof_pmc.sh, separate passes), wave-instructions per launch, mean over the second half of the launches",
+  "counters": {k: g(k) for k in keys}}, indent=1))
+PY
+  cp $OUT/${TAG}_${C}_valu.json $ROOT/profiles/${TAG}_${C}_valu.json
   # 2. kernel durations
   rm -rf /tmp/kt_$C
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$C -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --config $C > /tmp/kt_$C.log 2>&1

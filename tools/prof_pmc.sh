@@ -13,8 +13,11 @@ PASSES=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"
  "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU"
+ "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64"
  "FETCH_SIZE"
  "WRITE_SIZE"
+ "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
  "GRBM_GUI_ACTIVE"
 )
 i=0
