@@ -108,8 +108,21 @@ def render_sharded_device(plan, d_slice, width, waterfall=False, dst=0, group=No
     dev = d_slice.device
     slw = slice_width(width, world)
     P = L + binding.SP_CB_HIST_SIZE + 2
+    # one explicit stream for the library's kernels and the collectives (the null stream's handle is 0, which sp_context_set_stream
+    # reads as "use your own stream": the render would then not be ordered before the collectives)
     stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)                 # the library's kernels join torch's stream: collectives queue behind them
+    if stream.cuda_stream == 0:
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))   # whatever produced d_slice there
+    ctx.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        return _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, group, want_image, rank, world, slw, P)
+
+
+def _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, group, want_image, rank, world, slw, P):
+    ctx, n, L = plan.ctx, plan.n, plan.lut_len
+    dev = d_slice.device
+    d_slice.record_stream(stream)
     strip = torch.empty(max(4 * slw * n, 16), dtype=torch.uint8, device=dev)
     gauges = torch.empty(max(3 * slw, 16), dtype=torch.uint8, device=dev)
     record = torch.zeros(P, dtype=torch.int64, device=dev)

@@ -115,7 +115,12 @@ def _device_rank_main(rank, world, port, case_names, out_dir, backend):
     from spectroplot_js_amd import sharding
     g = goldenlib.Golden()
     ctx = pkg.Context(dev.index)
-    ok = True
+    bad = []
+
+    def chk(cond, what):
+        if not cond:
+            bad.append(what)
+
     for name in case_names:
         c, e = g.cases[name], g.expected[name]
         data = g.input(c)
@@ -127,24 +132,24 @@ def _device_rank_main(rank, world, port, case_names, out_dir, backend):
         m = sharding.render_sharded_device(plan, d_slice, c["width"], waterfall=c["waterfall"])
         L = len(lut)
         rec = m["record"].cpu().numpy()
-        ok &= [int(v) for v in rec[:L]] == e["merged"]["c_hist"]
+        chk([int(v) for v in rec[:L]] == e["merged"]["c_hist"], name + ": [int(v) for v in rec[:L]] == e['merged']['c_hist']")
         mm = rec[L + 1000:].view(np.float64)
         # the caller starts its merge from dBfs_min = 0, dBfs_max = -200 (spectroplot.js:1125-1126); every slice reply is already clamped so
-        ok &= goldenlib.same_f64(float(mm[0]), e["merged"]["dBfs_min"]) and goldenlib.same_f64(float(mm[1]), e["merged"]["dBfs_max"])
-        ok &= m["slice_width"] == e["merged"]["slice_width"]
-        ok &= goldenlib.sha256(m["strip"].cpu().numpy()) == e["slices"][rank]["rgba_sha256"]
+        chk(goldenlib.same_f64(float(mm[0]), e["merged"]["dBfs_min"]) and goldenlib.same_f64(float(mm[1]), e["merged"]["dBfs_max"]), name + ": goldenlib.same_f64(float(mm[0]), e['merged']['dBfs")
+        chk(m["slice_width"] == e["merged"]["slice_width"], name + ": m['slice_width'] == e['merged']['slice_width']")
+        chk(goldenlib.sha256(m["strip"].cpu().numpy()) == e["slices"][rank]["rgba_sha256"], name + ": goldenlib.sha256(m['strip'].cpu().numpy()) == e['s")
         slw = m["slice_width"]
         gz = m["gauges"].cpu().numpy()
         for k, key in enumerate(("gauge_mins", "gauge_maxs", "gauge_amps")):
-            ok &= gz[k * slw:(k + 1) * slw].tobytes().hex() == e["slices"][rank][key]
+            chk(gz[k * slw:(k + 1) * slw].tobytes().hex() == e["slices"][rank][key], name + ": gz[k * slw:(k + 1) * slw].tobytes().hex() == e['sl")
         if rank == 0:
-            ok &= m["image"].is_cuda and goldenlib.sha256(m["image"].cpu().numpy()) == e["merged"]["rgba_sha256"]
+            chk(m["image"].is_cuda and goldenlib.sha256(m["image"].cpu().numpy()) == e["merged"]["rgba_sha256"], name + ": m['image'].is_cuda and goldenlib.sha256(m['image']")
         else:
-            ok &= m["image"] is None
+            chk(m["image"] is None, name + ": m['image'] is None")
         plan.close()
     ctx.close()
     with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
-        f.write("ok" if ok else "FAIL")
+        f.write("ok" if not bad else "FAIL " + "; ".join(bad[:12]))
     dist.destroy_process_group()
 
 
