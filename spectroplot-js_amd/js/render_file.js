@@ -14,8 +14,11 @@ function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplo
  * With `byName: true`, `window` and `cmap` are option names (any spelling the reference's lookup accepts) and the slices go to the
  * workers as named requests (HipWorker.renderNamed -> sp_render_named): taper, block_norm and the end-forced colour map are evaluated
  * inside the library, once per worker while the names repeat.
+ * With `merge: false` the strips are not copied into one image (`data` is null; `replies` hold them): an image of 2^31 bytes or more -
+ * BASELINE config 5 is exactly 2^31 - is beyond what one typed array can hold under Node 12, as it is beyond one canvas.
  * @param {{buffer: ArrayBuffer, format: string, n: number, width: number, workers?: number, window?: string|{window, weight},
- *          cmap: number[][]|string, gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean, byName?: boolean}} o
+ *          cmap: number[][]|string, gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean, byName?: boolean,
+ *          merge?: boolean}} o
  * @returns {Promise<{data: Uint8ClampedArray, width, height, c_hist, cB_hist, dBfs_min, dBfs_max, sliceWidth, replies}>}
  */
 function renderSliced(o, pool) {
@@ -32,7 +35,7 @@ function renderSliced(o, pool) {
     const width = o.width, sliceWidth = ~~(width / workers)             // spectroplot.js:1208
     const own = !pool
     pool = pool || Array.from({ length: workers }, () => new HipWorker())
-    const merged = new Uint8ClampedArray(4 * width * n)
+    const merged = o.merge === false ? null : new Uint8ClampedArray(4 * width * n)
     const c_hist = new Array(cmap.length).fill(0), cB_hist = new Array(1000).fill(0)
     let dBfs_min = 0.0, dBfs_max = -200.0
     // one FIFO of resolvers per worker, like the reference's renderCallbacks (lib/spectroplot.js:89-98, :111-115)
@@ -69,6 +72,7 @@ function renderSliced(o, pool) {
             if (r.dBfs_max > dBfs_max) dBfs_max = r.dBfs_max
             for (let k = 0; k < 1000; k++) cB_hist[k] += r.cB_hist[k]
             for (let k = 0; k < cmap.length; k++) c_hist[k] += r.c_hist[k]
+            if (!merged) continue
             const img = r.imageData.data
             const [px, py, pw, ph] = stripPlacement(r, { width, sliceWidth, n, waterfall: !!o.waterfall })
             const canvasWidth = o.waterfall ? n : width

@@ -274,9 +274,11 @@ def test_random_requests_against_oracle(pkg, ctx, case):
     # BASELINE configs 3 and 5 at full size (1 GiB in / 1 GiB out; 192 MiB in / 2 GiB out)
     ("config3_full_cs16_n2048", "CS16", 28, 2048, None, "hann"),
     ("config5_full_cs12_n8192_zoom8", "CS12", 26, 8192, (1 << 26) // 8192 * 8, "blackmanHarris"),
+    # one full slice of BASELINE config 4: 2^28 cu8 samples (1/8 of the 2 GSample capture), 262 144 frames, 1 GiB of image
+    ("config4_full_slice_cu8_n1024", "CU8", 28, 1024, None, "blackmanHarris"),
 ], ids=lambda c: c[0])
 def test_baseline_config_shapes_sampled_frames(pkg, ctx, golden, cfg):
-    """The other BASELINE.json configurations (length scaled down, shape kept: format, n, hop / 8x overlap, window) on
+    """The other BASELINE.json configurations (scaled down and at full size: format, n, hop / 8x overlap, window) on
     device-generated input: histogram totals plus bit-exact comparison of sampled frames (image column, gauges) with the
     oracle, which renders each sampled frame from its own n samples (frames are independent given their start)."""
     name, fmt, lg, n, frames, wname = cfg

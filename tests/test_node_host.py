@@ -66,3 +66,11 @@ def test_named_requests_and_the_command_line_renderer():
     out = _node("check_named.js")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "named requests ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_config5_at_full_size_through_the_javascript_boundary():
+    """BASELINE config 5 (64 MSample cs12, n = 8192, zoom x8, 2 GiB of RGBA) through renderSliced with two HipWorker slices."""
+    out = _node("check_config5_full.js", timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "config 5 at full size through renderSliced ok" in out.stdout
