@@ -122,7 +122,7 @@ def rocprof_kernel_us(argv_config):
         best = None
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if any(k in row["Name"] for k in ("k_frames", "k_lds_r16", "k_scratch_radix2")):
+                if any(k in row["Name"] for k in ("k_frames", "k_scratch_radix2")):
                     t = float(row["TotalDurationNs"])
                     if best is None or t > best[0]:
                         best = (t, float(row["AverageNs"]) / 1e3, int(row["Calls"]), row["Name"].split("(")[0])
@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     ap.add_argument("--merge-every", type=int, default=16,
                     help="N > 1: the side-output records of this many renders travel in ONE all-gather (1 = one collective per render)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "lds", "frames"], help="A/B runs: force a device kernel")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "frames"], help="A/B runs: force a device kernel")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -197,9 +197,9 @@ int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int3
  */
 int sp_place_strips(sp_context *ctx, uint8_t *d_image, const uint8_t *d_strips, int32_t count, int32_t n, int32_t width,
                     int32_t slice_width, int32_t waterfall);
-/* Name of the kernel variant sp_plan_execute launches ("frames", "lds_r16", "scratch_radix2"). */
+/* Name of the kernel sp_plan_execute launches: "frames" (64 <= n <= 8192, LUT <= 256 entries) or "scratch_radix2" (everything else). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
-/* Forces a kernel variant (tests compare the device paths): 0 automatic, 1 scratch_radix2, 2 lds_r16, 3 frames. */
+/* Forces a kernel (tests compare the two device paths): 0 automatic, 1 scratch_radix2, 3 frames (2: removed, SP_ERR_UNSUPPORTED). */
 int sp_plan_force_kernel(sp_plan *plan, int32_t which);
 
 /*

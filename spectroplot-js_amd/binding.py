@@ -332,7 +332,7 @@ class Plan:
         return self.ctx.lib.L.sp_plan_kernel_name(self.h).decode()
 
     def force_kernel(self, which):
-        self.ctx._chk(self.ctx.lib.L.sp_plan_force_kernel(self.h, {"auto": 0, "scratch": 1, "lds": 2, "frames": 3}[which]))
+        self.ctx._chk(self.ctx.lib.L.sp_plan_force_kernel(self.h, {"auto": 0, "scratch": 1, "frames": 3}[which]))
 
     def execute(self, d_bytes, nbytes, width, rgba=0, gauge_mins=0, gauge_maxs=0, gauge_amps=0, c_hist=0, cb_hist=0, dbfs_minmax=0):
         """All pointer arguments are device addresses (ints); 0 skips that output. Asynchronous on the context's stream."""

@@ -15,7 +15,6 @@
 
 #include "../../include/spectroplot_hip.h"
 #include "sp_host.h"
-#include "sp_kernel_lds.h"
 #include "sp_kernel_frames.h"
 #include "sp_kernel_scratch.h"
 #include "sp_synth.h"
@@ -100,8 +99,8 @@ struct sp_plan {
     const double *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_gray_edge = nullptr, *d_cb_edge = nullptr;
     const uint32_t *d_lut = nullptr;
     const uint16_t *d_cell_g = nullptr, *d_cell_l = nullptr;   // merged-cell ranges per colour index / level (k_frames)
-    const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for the LDS kernel
-    int force_kernel = 0;           // 0 auto, 1 scratch, 2 lds_r16, 3 frames
+    const double2 *d_stage_tw = nullptr;   // per-stage twiddle tables for k_frames
+    int force_kernel = 0;           // 0 auto, 1 scratch, 3 frames
 };
 
 namespace {
@@ -482,9 +481,9 @@ extern "C" int sp_plan_create(sp_context *ctx, const sp_request *req, sp_plan **
     for (int i = 0; i < L; i++)
         lut32[(size_t)i] = (uint32_t)p->lut[3 * (size_t)i] | ((uint32_t)p->lut[3 * (size_t)i + 1] << 8)
                            | ((uint32_t)p->lut[3 * (size_t)i + 2] << 16) | 0xff000000u;
-    // per-stage twiddle tables for the LDS kernel: stage s (size 2^s) has 2^(s-1) entries (cos, sin), consecutive
+    // per-stage twiddle tables for k_frames: stage s (size 2^s) has 2^(s-1) entries (cos, sin), consecutive
     std::vector<double2> stage_tw;
-    if (spk::lds_kernel_supports(n)) {
+    if (spk::frame_parts_support(n)) {
         stage_tw.resize((size_t)n);   // entries 1 .. n-1 used: stage s starts at 2^(s-1)
         stage_tw[0] = make_double2(0, 0);
         for (int s = 1; s <= p->levels; s++) {
@@ -561,40 +560,33 @@ extern "C" void sp_plan_destroy(sp_plan *plan)
     delete plan;
 }
 
-// Both LDS kernels skip the products of (1, 0) butterflies on integer samples, which is exact only with a finite taper; both
-// take their first index guess from f32, which needs every edge inside the f32 range.
-static bool plan_lds_capable(const sp_plan *plan)
-{
-    return spk::lds_kernel_supports(plan->req.n) && plan->req.lut_len >= 2 && plan->req.lut_len <= spk::kLdsMaxLut
-           && plan->gray_b <= spk::kLdsMaxGrayB && plan->edges_in_f32 && plan->taper_finite;
-}
-
+// k_frames skips the products of (1, 0) butterflies on integer samples, which is exact only with a finite taper; it takes its
+// indices from an f32 scale, which needs every edge inside the f32 range and usable margins (sp_host.cpp); its first-pass twiddles
+// are literals, checked against this plan's table.
 static bool plan_frames_capable(const sp_plan *plan)
 {
-    return plan_lds_capable(plan) && spk2::frames_kernel_supports(plan->req.n, 8) && plan->th.frames_ok && plan->tw16_ok;
+    return spk2::frames_kernel_supports(plan->req.n) && plan->req.lut_len >= 2 && plan->req.lut_len <= spk::kLdsMaxLut
+           && plan->gray_b <= spk::kLdsMaxGrayB && plan->edges_in_f32 && plan->taper_finite && plan->th.frames_ok && plan->tw16_ok;
 }
 
-// 1 = scratch_radix2, 2 = lds_r16, 3 = frames
+// 1 = scratch_radix2, 3 = frames (2 was k_lds_r16, round 1's frame loop: removed in round 3)
 static int plan_kernel(const sp_plan *plan)
 {
     if (plan->force_kernel) return plan->force_kernel;
 #ifdef SP_EXPERIMENT_KNOBS
     static const int env_kernel = getenv("SP_FORCE_KERNEL") ? atoi(getenv("SP_FORCE_KERNEL")) : 0;
     if (env_kernel == 3 && plan_frames_capable(plan)) return 3;
-    if (env_kernel == 2 && plan_lds_capable(plan)) return 2;
     if (env_kernel == 1) return 1;
 #endif
-    // k_frames is the default, k_lds_r16 its predecessor (kept for A/B runs and as a second device path in the tests); the
-    // scratch kernel covers every request the LDS kernels do not.
+    // k_frames is the fast path; the scratch kernel covers every request it does not
     if (plan_frames_capable(plan)) return 3;
-    if (plan_lds_capable(plan)) return 2;
     return 1;
 }
 
 extern "C" int sp_plan_force_kernel(sp_plan *plan, int32_t which)
 {
     if (!plan || which < 0 || which > 3) return SP_ERR_INVALID_ARG;
-    if (which == 2 && !plan_lds_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "k_lds_r16 does not cover this request");
+    if (which == 2) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "k_lds_r16 is no longer part of the library");
     if (which == 3 && !plan_frames_capable(plan)) return fail(plan->ctx, SP_ERR_UNSUPPORTED, "k_frames does not cover this request");
     plan->force_kernel = which;
     return SP_OK;
@@ -605,7 +597,6 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
     if (!plan) return "";
     switch (plan_kernel(plan)) {
     case 3: return "frames";
-    case 2: return "lds_r16";
     default: return "scratch_radix2";
     }
 }
@@ -749,9 +740,6 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
 #endif
         rc = spk2::launch_frames(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, ctx->device, s);
         if (rc) return fail(ctx, rc, "k_frames launch rejected the configuration");
-    } else if (which == 2) {
-        rc = spk::launch_lds(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, ctx->device, s);
-        if (rc) return fail(ctx, rc, "LDS kernel launch rejected the configuration");
     } else {
         // scratch slabs: one per workgroup, capped at 256 MiB
         long long blocks = (256ll << 20) / (16ll * n);

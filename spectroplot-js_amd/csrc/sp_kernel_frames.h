@@ -1,44 +1,40 @@
-// sp_kernel_frames.h — the frame-loop kernel for 64 <= n <= 8192 (gfx950), second generation.
+// sp_kernel_frames.h — the frame-loop kernel for 64 <= n <= 8192 (gfx950).
 //
-// Same job and same butterfly graph as k_lds_r16 (sp_kernel_lds.h; lib/worker.js:68-137, lib/fft_nayuki.js:54-96), rebuilt
-// around what bounds it on MI355X.  tools/op_cost.hip (profiles/r02_op_cost.txt): an f64 multiply or add costs 4.4-4.7 issue
-// cycles per wave-instruction per SIMD whatever the occupancy, v_permlane32_swap 8, v_log_f32 8.5, conversions / floor / fract /
-// compares 4.4, 32-bit integer and f32 multiply-add 2.5; one wave alone reaches half of that, two waves reach it.  The reference's
-// unfused butterflies are 800 f64 wave-instructions per 1024-point frame, so the loop is bound by VALU issue, not by HBM, LDS
-// or latency, and every change here moves work off the VALU or removes it:
+// lib/worker.js:68-137 per frame (decode, taper, the butterfly graph of lib/fft_nayuki.js:54-96, |X|^2 -> dB -> indices -> RGBA, side
+// outputs), built from the parts of sp_frame_parts.h around what bounds it on MI355X.  tools/op_cost.hip (profiles/r02_op_cost.txt): an
+// f64 multiply or add costs 4.4-4.7 issue cycles per wave-instruction per SIMD whatever the occupancy, v_permlane32_swap 8, v_log_f32
+// 8.5, conversions / floor / fract / compares 4.4, 32-bit integer and f32 multiply-add 2.5; one wave alone reaches half of that, two
+// waves reach it.  The reference's unfused butterflies are 800 f64 wave-instructions per 1024-point frame, so the loop is bound by
+// VALU issue, not by HBM, LDS or latency, and the design moves work off the VALU or removes it:
 //   * first pass (stages 1-4): its eight twiddles cos / sin(2 pi k / 16) are the same doubles for every n >= 16 (the table
 //     index k*n/16 is scaled by a power of two before the division by n), so they are literals: no LDS reads, no registers;
 //     the butterflies whose twiddle is (1, 0) skip their products when the frame is finite (integer formats always; float
 //     frames after one f32 multiply-add per raw word), the ones whose sine is exactly 1 skip two products always;
 //   * the re-distribution between passes goes through a padded, wave-private LDS buffer; at n = 512 / 1024 the second one is a
 //     register transpose (v_permlane16_swap / v_permlane32_swap: what it costs the VALU the LDS round trip costs the LDS pipe);
+//   * input: the raw words of the NEXT frame are requested right after the current frame is decoded (1-, 2-, 3-, 4-, 8-byte samples);
 //   * epilogue: colour index and centi-bel level are floor(a + b*log2(|X|^2)) in f32; a lane is sent to the exact edge tables
 //     only if its f32 value lies within a proven error margin of an integer (a few lanes in ten thousand), so the common path has
 //     no LDS read and no f64 compare; one histogram atomic per pixel on the merged cell (colour index + level), which the
-//     finish kernel turns back into the two histograms;
+//     finish kernel turns back into the two histograms; one colour byte per pixel into an LDS tile [frame][bin]; frame extremes of
+//     |X|^2 by LDS integer atomics on the bit patterns;
+//   * after a group of frames the workgroup writes the tile out through the RGBA LUT as 16-byte stores (128-byte row segments in
+//     spectrogram layout, whole rows in waterfall layout), in two slices around the passes of the next group's first frame;
 //   * n >= 2048 (a frame spans several waves): the waves of a frame meet through an LDS counter, announced early and waited for
 //     late where the dataflow allows, instead of the workgroup barrier;
 //   * the workgroup's last write-out is split between the first and the second waves of the SIMDs (n = 1024): the first ones
 //     finish ~7 us earlier and write their half meanwhile.
-// Everything else (input prefetch, exchange buffer, tile and write-out, per-frame extremes) follows k_lds_r16.
-// Macros SP_X_* select measured alternatives in libraries built by tools/build_variant.sh; SP_ABL_* remove a
-// piece for cost attribution (results invalid); SP_STAMPS adds the per-wave clocks tools/stamps.py reads.  None is set in the product.
+// Measured alternatives (three waves per SIMD, two workgroups per CU, LDS-DMA input, other batch / slice / chain counts) are recorded in
+// DESIGN.md section 6.2; the cost-attribution switches and per-wave clock stamps that produced profiles/ live in
+// tools/experiments/frames_instrumentation.patch (tools/build_variant.sh applies it), not here.
 #pragma once
 
+#include <atomic>
 #include <cstdio>
 
-#include "sp_kernel_lds.h"
+#include "sp_frame_parts.h"
 
 // experiment switches of the large-n layout (defaults = the shipped kernel)
-#ifndef SP_X_BIG_FROM
-#define SP_X_BIG_FROM 2048
-#endif
-#ifndef SP_X_TWMAX_BIG
-#define SP_X_TWMAX_BIG 9
-#endif
-#ifndef SP_X_TILE_BIG
-#define SP_X_TILE_BIG 65536
-#endif
 
 namespace spk2 {
 
@@ -78,27 +74,25 @@ __host__ __device__ inline constexpr int mm_slots(int n)
     return lds_mm_slots(n) < kMmSlotsMax ? lds_mm_slots(n) : kMmSlotsMax;
 }
 
-__host__ __device__ inline bool frames_kernel_supports(int n, int waves)
-{
-    if (!lds_kernel_supports(n)) return false;
-    const int threads = waves * 64, T = n / 16;
-    return T <= threads && threads % T == 0;
-}
+constexpr int kFrameThreads = 512;   // one workgroup per CU: eight waves, two per SIMD
+
+// 16 points per thread, whole frames per workgroup: 64 <= n <= 8192
+__host__ __device__ inline bool frames_kernel_supports(int n) { return frame_parts_support(n); }
 
 // n >= 2048: the twiddle tables of stages 1-9 only stay in LDS (stage 10 joins the later ones in L2: two more loads per thread and
 // frame), which makes room for a 64 KiB tile: 32 / 16 / 8 frames per group instead of 16 / 8 / 4, i.e. 128 / 64 / 32-byte pieces of
 // the image rows and half as many group barriers (config 5 wrote 2.1 x its image with 16-byte pieces; config 3: -0.7 %, cf32 at
 // n = 2048: -5 %, config 5: -5 %)
-__host__ __device__ inline constexpr int frames_tw_max_stage(int n) { return n >= SP_X_BIG_FROM ? SP_X_TWMAX_BIG : kLdsTwMaxStage; }
+__host__ __device__ inline constexpr int frames_tw_max_stage(int n) { return n >= 2048 ? 9 : kLdsTwMaxStage; }
 __host__ __device__ inline constexpr int frames_tw_entries(int n) { return n < (1 << frames_tw_max_stage(n)) ? n : (1 << frames_tw_max_stage(n)); }
 
 // frames per output group (tile height): a multiple of the frames per round and of 4 (the write-out handles frame quads)
-__host__ __device__ inline int group_frames_for(int n, int want, int threads)
+__host__ __device__ inline int group_frames_for(int n, int want)
 {
-    const int fpb = threads * 16 / n;
+    const int fpb = kFrameThreads * 16 / n;
     int unit = fpb;
     while (unit % 4) unit *= 2;          // lcm(fpb, 4) for fpb in {1, 2, 3, 6, 12, ...}
-    int cap = (n >= SP_X_BIG_FROM ? SP_X_TILE_BIG : 32768) / n;
+    int cap = (n >= 2048 ? 65536 : 32768) / n;
     if (cap > want) cap = want;
     int f = cap / unit * unit;
     if (f < unit) f = unit;
@@ -109,14 +103,14 @@ struct Layout {
     int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_win, total;
 };
 
-__host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, int threads, bool edges_lds, bool win_lds = true)
+__host__ __device__ inline Layout layout(int n, int lut_len, int group_frames)
 {
     Layout l;
-    const int fpb = threads * 16 / n;
+    const int fpb = kFrameThreads * 16 / n;
     int o = fpb * (n + n / 16) * 8;                              // exchange buffers
     l.off_tw = o;     o += frames_tw_entries(n) * 16;
-    l.off_gedge = o;  o += edges_lds ? lut_len * 8 : 0;
-    l.off_cbedge = o; o += edges_lds ? (SP_CB_HIST_SIZE + 1) * 8 : 0;
+    l.off_gedge = o;  o += lut_len * 8;                          // exact edge tables (read by the few lanes the f32 test sends there)
+    l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
     o = (o + 15) & ~15;
     l.off_mm = o;     o += group_frames * mm_slots(n) * 2 * 8;
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
@@ -124,7 +118,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames, i
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
     l.off_done = o;   o += 32;                                   // arrival counters: the two wave sets (last write-out), the frames' waves
     o = (o + 7) & ~7;
-    l.off_win = o;    o += (win_lds && lds_win_in_lds(n)) ? n * 8 : 0;
+    l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
     return l;
 }
@@ -202,23 +196,6 @@ __device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_
     return __ballot(s != s) != 0ull;
 }
 
-// Diagnostic builds (-DSP_STAMPS): shader-clock sums per wave between points where the wave has no LDS / memory operation to wait
-// for anyway (s_memtime returns through lgkmcnt).  No stamp executes in the product build.
-#ifdef SP_STAMPS
-#define SP_PIN8(v, o) asm volatile("" : "+v"(v[o]), "+v"(v[o + 1]), "+v"(v[o + 2]), "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), "+v"(v[o + 7]));
-#define SP_STAMP(k)                                                   \
-    {                                                                 \
-        SP_PIN8(re, 0) SP_PIN8(re, 8) SP_PIN8(im, 0) SP_PIN8(im, 8)    \
-        unsigned long long now_;                                      \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-        stamp_sum[k] += now_ - stamp_last;                            \
-        stamp_last = now_;                                            \
-    }
-#define SP_TAIL_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tail_stamp[k]) :: "memory");
-#else
-#define SP_STAMP(k)
-#define SP_TAIL_STAMP(k)
-#endif
 
 // The waves that share a frame (n = 2048: two, n = 4096: four) meet through an LDS counter instead of the workgroup barrier, which
 // held every frame of a round to the pace of the slowest wave and kept all waves in the same phase (all in the VALU, then all in the
@@ -229,9 +206,6 @@ struct FrameMeet {
     unsigned addr;     // LDS byte address of the frame's counter (wave-uniform)
     unsigned target;   // the count once every wave of the frame has arrived the next time
     unsigned step;     // waves per frame
-#ifdef SP_STAMPS
-    unsigned long long spent = 0;   // shader clocks inside wait()
-#endif
     // One asm block each (a C loop around an atomic splits the kernel's big basic blocks and costs the register allocator 60+ spilled
     // VGPRs).  arrive(): lane 0 adds one.  wait(): the wave polls until every wave of the frame has arrived as often as itself.
     // A wave alternates arrive and wait strictly, so no wave is ever two arrivals ahead and the count cannot be reached early.
@@ -256,10 +230,6 @@ struct FrameMeet {
         if constexpr (COUNTER) {
             target = (unsigned)__builtin_amdgcn_readfirstlane((int)(target + step));   // wave-uniform, kept in an SGPR
             unsigned a_v, got_v, got_s;
-#ifdef SP_STAMPS
-            unsigned long long t0_, t1_;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
-#endif
             asm volatile("v_mov_b32 %[a_v], %[addr]\n"
                          "L_sp_meet_%=:\n\t"
                          "ds_read_b32 %[got_v], %[a_v]\n\t"
@@ -271,10 +241,6 @@ struct FrameMeet {
                          : [a_v] "=&v"(a_v), [got_v] "=&v"(got_v), [got_s] "=&s"(got_s)
                          : [addr] "s"(addr), [target] "s"(target)
                          : "memory", "scc");
-#ifdef SP_STAMPS
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
-            spent += t1_ - t0_;
-#endif
         } else {
             spk::frame_sync<BLOCK_SYNC>();
         }
@@ -286,62 +252,28 @@ struct FrameMeet {
     }
 };
 
-template <int LOG2N, bool CH, int PFB, int WAVES, bool EDGES_LDS>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
+template <int LOG2N, bool CH, int PFB>
+__global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, const int format, const double2 *__restrict__ stage_tw,
                                                        const int group_frames, const int groups)
 {
-    constexpr int kThreads = WAVES * 64;
+    constexpr int kThreads = kFrameThreads;   // eight waves, two per SIMD, one workgroup per CU
     constexpr int N = 1 << LOG2N;
     constexpr int T = N / 16;                       // threads per frame
     constexpr int FPB = kThreads / T;               // frames per round
     constexpr bool BLOCK_SYNC = T > 64;
     constexpr int TWMAX = frames_tw_max_stage(N);
     constexpr int NPASS = (LOG2N + 3) / 4;
-#ifndef SP_X_STAGED
-#define SP_X_STAGED 0
-#endif
-#ifndef SP_X_COUNTER_ALL
-#define SP_X_COUNTER_ALL 0
-#endif
-#ifndef SP_X_COUNTER_SYNC
-#define SP_X_COUNTER_SYNC 1
-#endif
-#ifndef SP_X_HALVES
-#define SP_X_HALVES 1
-#endif
-#ifndef SP_X_BIG8
-#define SP_X_BIG8 2   // 8-byte samples at n >= 2048: 1 = stage-by-stage twiddles, 2 = samples requested at frame start (no spills; cf32 n = 2048: 411 -> 358 us per 32 768 frames)
-#endif
-#ifndef SP_X_BATCH
-#define SP_X_BATCH 2   // bins per epilogue batch (one exact-path branch per batch): 2 measured best (4: config 4 +3 %, config 5 +2.5 %; 8: +5 %; 16: spills)
-#endif
-#ifndef SP_X_LATEPF
-#define SP_X_LATEPF 0
-#endif
-#ifdef SP_STAMPS
-    unsigned long long stamp_entry, stamp_entry_rt;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry), "=s"(stamp_entry_rt) :: "memory");
-    unsigned long long pro_stamp[3] = {0, 0, 0};
-#define SP_PRO_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_stamp[k]) :: "memory");
-#else
-#define SP_PRO_STAMP(k)
-#endif
-    constexpr bool STAGED = PFB == 0 || WAVES > 8 || SP_X_STAGED || (SP_X_BIG8 & 1 && PFB == 8 && LOG2N >= 11);  // generic loaders, 3 waves per SIMD: no registers for whole-pass twiddle batches
-    // 3 waves per SIMD: no register prefetch across frames (the compiler parks those registers in scratch); a frame's samples are
-    // requested when it starts and the other waves of the SIMD cover the latency
-    constexpr bool LATE_PF = WAVES > 8 || SP_X_LATEPF || (SP_X_BIG8 & 2 && PFB == 8 && LOG2N >= 11);
-    // 3 waves per SIMD at n = 1024 (one wave per frame): the next frame's raw samples travel HBM -> LDS by LDS-DMA
-    // (global_load_lds_dwordx4: no registers) into the frame's exchange buffer, which is idle once the first exchange has been
-    // read back (the second one is a register transpose); the taper comes from L2 at the top of a frame.
-    constexpr bool DMA = WAVES > 8 && LOG2N == 10 && !CH && (PFB == 8 || PFB == 4 || PFB == 2 || PFB == 1);
+    constexpr bool STAGED = PFB == 0;   // the generic loaders leave no registers for a whole pass's twiddles: read stage by stage
+    // 8-byte samples at n >= 2048: a frame's samples are requested when it starts, not one frame ahead (the prefetch registers of
+    // the next frame were what spilled there: cf32, n = 2048: 411 -> 358 us per 32 768 frames); its partner wave covers the latency
+    constexpr bool LATE_PF = PFB == 8 && LOG2N >= 11;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Layout lay = layout(N, a.lut_len, group_frames, kThreads, EDGES_LDS, WAVES == 8);
-    static_assert(WAVES == 4 || WAVES == 8 || WAVES == 12, "workgroup shapes: 4 (two per CU), 8, 12 waves");
+    const Layout lay = layout(N, a.lut_len, group_frames);
     double *s_xch = (double *)smem;
     double2 *s_tw = (double2 *)(smem + lay.off_tw);
-    const double *edge_g = EDGES_LDS ? (const double *)(smem + lay.off_gedge) : a.gray_edge;
-    const double *edge_cb = EDGES_LDS ? (const double *)(smem + lay.off_cbedge) : a.cb_edge;
+    const double *edge_g = (const double *)(smem + lay.off_gedge);
+    const double *edge_cb = (const double *)(smem + lay.off_cbedge);
     unsigned long long *s_mm = (unsigned long long *)(smem + lay.off_mm);
     unsigned char *s_tile = smem + lay.off_tile;
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
@@ -353,7 +285,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     const int fs = tid / T;                         // frame slot within a round
     const int tl = tid % T;                         // thread within the frame
     double *xbuf = s_xch + fs * (N + N / 16);
-    constexpr bool COUNTER_SYNC = SP_X_COUNTER_SYNC && BLOCK_SYNC && (T < kThreads || SP_X_COUNTER_ALL);   // a frame's waves are not the whole workgroup
+    constexpr bool COUNTER_SYNC = BLOCK_SYNC && T < kThreads;   // a frame's waves are not the whole workgroup (n = 2048, 4096)
     FrameMeet<COUNTER_SYNC, BLOCK_SYNC> meet{
         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) unsigned int *)(s_done + 2 + fs)),
         0u, (unsigned)(T / 64)};
@@ -367,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 
     constexpr bool PF = PFB != 0;
     const int sidx_pf = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
-    const int rounds = (group_frames + FPB - 1) / FPB;   // the last round may fill only part of the slots (12 waves, 32 frames)
+    const int rounds = (group_frames + FPB - 1) / FPB;
     uint32_t raw_lo[PF ? 16 : 1], raw_hi[PFB == 8 ? 16 : 1];
     int raw_back = 0;
     auto request = [&](int xq) {
@@ -378,36 +310,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
         }
     };
-    // LDS-DMA of frame xq into this wave's exchange buffer: 16-byte granules from the granule that holds the frame's first byte;
-    // dma_off is that byte's offset in its granule (the decode reads from there)
-    int dma_off = 0;
-    auto dma_request = [&](int xq) {
-        if constexpr (DMA) {
-            const int xc = xq < a.x_end ? xq : a.x_end - 1;
-            const int64_t byte0 = (int64_t)frame_start(a.stride, xc) * PFB;
-            dma_off = (int)(byte0 & 15);
-            const uint8_t *src = a.bytes + (byte0 - dma_off) + lane * 16;
-            const int total = N * PFB + dma_off;
-            constexpr int CHUNKS = (N * PFB + 15 + 1023) / 1024;
-#pragma unroll
-            for (int j = 0; j < CHUNKS; j++) {
-                if (j * 1024 + lane * 16 < total)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
-                                                     (__attribute__((address_space(3))) void *)((unsigned char *)xbuf + j * 1024), 16, 0, 0);
-            }
-        }
-    };
-    // (SP_X_HALVES) the first / second waves of the SIMDs each take one half of a group's frames
-    const bool HALVES = SP_X_HALVES && WAVES == 8 && T == 64 && group_frames == 32;
+    // n = 1024, 32-frame groups: the first / second waves of the SIMDs each take one half of a group's frames
+    const bool HALVES = T == 64 && group_frames == 32;
     const int fs0 = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + fs % (FPB / 2) : fs;     // the slot's frame in a group's first round
-    if (DMA && xcd * chunk + lane_in_xcd < g_end) dma_request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
     if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
 
-    // two 4-wave workgroups per CU (80 KiB of LDS each): the taper does not fit and is re-read from L2 like in the DMA variant
-    constexpr bool WIN_GLOBAL = DMA || (WAVES == 4 && lds_win_in_lds(N));
-    constexpr bool WIN_LDS = lds_win_in_lds(N) && !WIN_GLOBAL;
+    constexpr bool WIN_LDS = lds_win_in_lds(N);   // taper in LDS for n <= 1024, in registers for the whole launch above
     double *s_win = (double *)(smem + lay.off_win);
-    SP_PRO_STAMP(0)   // kernel arguments read, the first frame's samples requested
     constexpr int MMS = mm_slots(N);
     {
         // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
@@ -429,14 +338,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             tw_r[k] = i < NTW ? stage_tw[i] : make_double2(0.0, 0.0);
         }
         const unsigned int lut_r = tid < a.lut_len ? a.lut_rgba[tid] : 0u;       // lut_len <= 256 < kThreads
-        double ge_r = 0.0, cb_r[(SP_CB_HIST_SIZE + kThreads) / kThreads];
-        if constexpr (EDGES_LDS) {
-            ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;
+        double cb_r[(SP_CB_HIST_SIZE + kThreads) / kThreads];
+        const double ge_r = tid < a.lut_len ? a.gray_edge[tid] : 0.0;
 #pragma unroll
-            for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
-                const int i = tid + k * kThreads;
-                cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
-            }
+        for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
+            const int i = tid + k * kThreads;
+            cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
         }
         // what needs no table is set up while the loads are in flight (a table load takes ~2.3 us at the start of a launch)
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
@@ -451,15 +358,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             if (i < NTW) s_tw[i] = tw_r[k];
         }
         if (tid < a.lut_len) s_lut[tid] = lut_r;
-        if constexpr (EDGES_LDS) {
-            if (tid < a.lut_len) ((double *)(smem + lay.off_gedge))[tid] = ge_r;
+        if (tid < a.lut_len) ((double *)(smem + lay.off_gedge))[tid] = ge_r;
 #pragma unroll
-            for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
-                const int i = tid + k * kThreads;
-                if (i <= SP_CB_HIST_SIZE) ((double *)(smem + lay.off_cbedge))[i] = cb_r[k];
-            }
+        for (int k = 0; k < (SP_CB_HIST_SIZE + kThreads) / kThreads; k++) {
+            const int i = tid + k * kThreads;
+            if (i <= SP_CB_HIST_SIZE) ((double *)(smem + lay.off_cbedge))[i] = cb_r[k];
         }
-        SP_PRO_STAMP(1)   // the tables have arrived (their LDS stores are issued)
         if constexpr (WIN_LDS) {
 #pragma unroll
             for (int k = 0; k < WINK; k++) {
@@ -470,19 +374,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     }
 
     const double *const wbase = s_win + tl;   // stored as the threads read it: entry e*T + tl = taper[rev4(e)*T + rev(tl)]
-    double win_reg[(WIN_LDS || WIN_GLOBAL) ? 1 : 16];
-    if constexpr (WIN_GLOBAL) {
-        // nothing resident: 16 loads per frame from L2
-    } else if constexpr (WIN_LDS) {
-        // loaded with the tables above
-    } else {
+    double win_reg[WIN_LDS ? 1 : 16];
+    if constexpr (!WIN_LDS) {
         const int sidx = (int)(__brev((unsigned)tl) >> (32 - (LOG2N - 4)));
 #pragma unroll
         for (int e = 0; e < 16; e++) win_reg[e] = a.window[rev4(e) * T + sidx];
     }
-#ifdef SP_X_SETPRIO
-    if ((tid >> 8) == 1) __builtin_amdgcn_s_setprio(SP_X_SETPRIO);   // the second wave of every SIMD
-#endif
     lds_barrier();
 
     const spfmt::View view{a.bytes, a.nbytes, a.nelem};
@@ -547,11 +444,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #pragma unroll
                         for (int j = 0; j < 4; j++)
 #pragma unroll
-#ifdef SP_ABL_NOLUT
-                            for (int k = 0; k < 4; k++) px[u][j][k] = ((gb[u][k] >> (8 * j)) & 0xff) * 0x010101u | 0xff000000u;
-#else
                             for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
-#endif
                     if (a.rgba_fast) {
                         // rows are 16-byte aligned, the width is a multiple of 4 and the image is below 4 GiB: 32-bit offsets from the
                         // uniform base (24-bit multiplies), no per-store checks
@@ -564,12 +457,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                             for (int j = 0; j < 4; j++) {
                                 const unsigned y = (y0 - (unsigned)(j * T)) & (N - 1);
                                 const unsigned off = (__umul24(y, (unsigned)a.width) + (unsigned)xa) * 4u;
-#ifdef SP_ABL_NOSTORE
-                                if (px[u][j][0] != 0x12345678u) continue;
-#endif
-#ifdef SP_ABL_HALFSTORE   // probe: do the stores of the other workgroups get cheaper when half of them store nothing?
-                                if (((blockIdx.x >> 3) & 1) && px[u][j][0] != 0x12345678u) continue;
-#endif
                                 // written once, never read by this kernel: non-temporal where a group's row segments are whole
                                 // 128-byte lines, so that the image does not displace the capture's lines in L2 (measured: 2.5 % of the
                                 // kernel at n = 1024); shorter segments (large n) are pieces of lines that L2 has to merge with the
@@ -589,9 +476,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                             const int i = i0v[u] + j * T;
                             const int y = (N / 2 - i) & (N - 1);
                             uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
-#ifdef SP_ABL_NOSTORE
-                            if (px[u][j][0] != 0x12345678u) continue;
-#endif
                             if (xa + 3 < a.x_end && (((size_t)dst & 15) == 0)) {
                                 *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             } else {
@@ -626,24 +510,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
     auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, true, group_frames >= 32); };
     int drain_x0 = -1;
     meet.arrive();   // the first re-distribution only waits (exchange<.., SECOND = false>)
-#ifdef SP_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64(), stamp_slow = 0;
-    const unsigned long long stamp_begin = stamp_last;
-#endif
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = a.frame0 + g * group_frames;
         for (int r = 0; r < rounds; r++) {
-#ifdef SP_X_STAGGER
-            // experiment: the second wave of every SIMD starts each group late, so that the two are in different phases
-            if (r == 0 && (tid >> 8) == 1)
-                for (int q = 0; q < SP_X_STAGGER; q++) __builtin_amdgcn_s_sleep(32);
-#endif
-#ifdef SP_X_ALTPRIO
-            // issue arbitration favours the older wave of a SIMD, which then waits for the younger one at the group's barrier: the two
-            // take turns at the higher priority, round by round
-            if (((r + (tid >> 8)) & 1) != 0) __builtin_amdgcn_s_setprio(SP_X_ALTPRIO);
-            else __builtin_amdgcn_s_setprio(0);
-#endif
             // HALVES: the first waves of the SIMDs (slots 0 .. FPB/2-1) own the group's first half of the frames, the second waves the
             // other half, so that each set can write its half out by itself after the workgroup's last group
             const int fr = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + r * (FPB / 2) + fs % (FPB / 2) : r * FPB + fs;
@@ -656,49 +525,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             double re[16], im[16];
             double win[16];
             bool nonfinite = true;   // wave-uniform
-            if constexpr (WIN_GLOBAL) {
-                // re-read every frame (L2 hits); the offset is hidden from the optimiser so that it does not keep the 16 values in
-                // registers across the frame loop
-                unsigned w_off = 0;
-                asm volatile("" : "+s"(w_off));
-                const char *wp = (const char *)(a.window + w_off);
-                // one per-lane offset register; the 16 entries are T*8 bytes apart, addressed by instruction offsets around the
-                // middle one (the offset field of a global load is 13 bits, signed)
-                unsigned w_lane = (unsigned)sidx_pf * 8u + 15u * T * 4u;
-                asm volatile("" : "+v"(w_lane));
 #pragma unroll
-                for (int e = 0; e < 16; e++) win[e] = *(const double *)(wp + w_lane + (rev4(e) * T * 8 - 15 * T * 4));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
-            }
+            for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
             // the frame this slot processes next: the same slot one round on, or its frame in the workgroup's next group
             const int xn = (r + 1 < rounds && (HALVES || fr + FPB < group_frames)) ? xr + (HALVES ? FPB / 2 : FPB)
                                                                          : (g + per_xcd < g_end ? a.frame0 + (g + per_xcd) * group_frames + fs0 : -1);
-            if constexpr (DMA) {
-                // the samples are in the exchange buffer once the wave's LDS-DMA operations have landed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // one address register (this lane's sample of the first run), instruction offsets for the other 15 runs
-                unsigned raw_lane = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)xbuf + (unsigned)dma_off
-                                    + (unsigned)sidx_pf * PFB;
-                asm volatile("" : "+v"(raw_lane));
-                const __attribute__((address_space(3))) unsigned char *rawb = (const __attribute__((address_space(3))) unsigned char *)(size_t)raw_lane;
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int off = rev4(e) * T * PFB;
-                    if constexpr (PFB == 8) {
-                        const unsigned long long w = *(const __attribute__((address_space(3))) unsigned long long *)(rawb + off);
-                        raw_lo[e] = (uint32_t)w;
-                        raw_hi[e] = (uint32_t)(w >> 32);
-                    } else if constexpr (PFB == 4) {
-                        raw_lo[e] = *(const __attribute__((address_space(3))) uint32_t *)(rawb + off);
-                    } else if constexpr (PFB == 2) {
-                        raw_lo[e] = *(const __attribute__((address_space(3))) uint16_t *)(rawb + off);
-                    } else {
-                        raw_lo[e] = rawb[off];
-                    }
-                }
-            } else if constexpr (PF && LATE_PF) request(xr);
+            if constexpr (PF && LATE_PF) request(xr);
             if constexpr (PF) {
                 if constexpr (PFB == 1) {
                     if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
@@ -738,13 +570,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 }
             }
 
-            SP_STAMP(0)   // loop head, taper reads, wait for the samples, decode
             unsigned tw_off = 0;
             asm volatile("" : "+s"(tw_off));
             const double2 *tw = stage_tw + tw_off;
-            if (SP_DRAIN_PARTS > 1 && drain_x0 >= 0) {
+            // the previous group's write-out goes in two slices around this frame's passes, so that its stores drain while the SIMDs compute
+            if (drain_x0 >= 0) {
                 lds_barrier();
-                drain(drain_x0, 0, SP_DRAIN_PARTS);
+                drain(drain_x0, 0, 2);
             }
             // ---- first pass: literal twiddles ------------------------------------------------------------------------------
             if constexpr (PFB == 0) {
@@ -755,7 +587,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             } else {
                 fft_pass1<true>(re, im);             // integer samples times a finite taper (sp_api.hip: plan_frames_capable)
             }
-            if (SP_DRAIN_PARTS >= 3 && drain_x0 >= 0) drain(drain_x0, 1, SP_DRAIN_PARTS);
             if constexpr (NPASS >= 2) {
                 constexpr int WS1 = LOG2N >= 8 ? 4 : LOG2N - 4;
                 constexpr int E1 = LOG2N >= 8 ? 8 : LOG2N;
@@ -765,37 +596,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 exchange<0, WS1, BLOCK_SYNC, false>(re, b0, b1, meet);
                 exchange<0, WS1, BLOCK_SYNC, true>(im, b0, b1, meet);
                 exchange_wait(re, im);
-                if constexpr (DMA) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the buffer has returned
-                    if (xn >= 0) dma_request(xn);                       // in flight until the next frame starts
-                }
-                SP_STAMP(1)   // (first write-out slice,) first pass, first exchange
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1, TWMAX>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
-                if (SP_DRAIN_PARTS >= 4 && drain_x0 >= 0) drain(drain_x0, 2, SP_DRAIN_PARTS);
                 if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
                     PassTw<WS2, 9, STAGED ? 8 : E2, TWMAX> tw2;
                     if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
-#ifndef SP_X_LDS_E2
                     if constexpr (LOG2N == 9 || LOG2N == 10) {
                         // two register bits against lane bits 4 / 5: v_permlane16_swap / v_permlane32_swap.  The swaps cost the VALU
                         // about what the LDS round trip costs the LDS pipe (measured: 1.2 % of the kernel in favour of the swaps)
                         exchange_permlane<LOG2N>(re);
                         exchange_permlane<LOG2N>(im);
-                    } else
-#endif
-                    {
+                    } else {
                         exchange<WS1, WS2, BLOCK_SYNC, false>(re, b1, b2, meet);
                         exchange<WS1, WS2, BLOCK_SYNC, true>(im, b1, b2, meet);
-                exchange_wait(re, im);
+                        exchange_wait(re, im);
                     }
-                    SP_STAMP(2)   // second pass, second exchange
                     if constexpr (STAGED) fft_pass_staged<WS2, 9, E2, TWMAX>(re, im, tl, s_tw, tw);
                     else fft_pass<WS2, 9, E2>(re, im, tw2);
-                    SP_STAMP(3)   // third pass
                     if constexpr (NPASS >= 4) {
                         constexpr int WS3 = LOG2N - 4;
                         double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
@@ -803,14 +623,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                         load_pass_tw(tw3, tl, s_tw, tw);
                         exchange<WS2, WS3, BLOCK_SYNC, false>(re, b2, b3, meet);
                         exchange<WS2, WS3, BLOCK_SYNC, true>(im, b2, b3, meet);
-                exchange_wait(re, im);
+                        exchange_wait(re, im);
                         fft_pass<WS3, 13, LOG2N>(re, im, tw3);
                     }
                 }
             }
             // now register e of thread tl holds bin i = tl + e*T
 
-            if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS (as k_lds_r16)
+            if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
                 double pp[16];
                 meet.wait();   // (announced after the last re-distribution's reads)
 #pragma unroll
@@ -853,12 +673,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             }
 
             if (drain_x0 >= 0) {
-                if (SP_DRAIN_PARTS == 1) lds_barrier();
-                drain(drain_x0, SP_DRAIN_PARTS - 1, SP_DRAIN_PARTS);
+                drain(drain_x0, 1, 2);
                 lds_barrier();
                 drain_x0 = -1;
             }
-            SP_STAMP(4)   // last write-out slice and its barrier
             // ---- |X|^2 -> colour index, centi-bel level ---------------------------------------------------------------------
             // t = a + b*log2((float)|X|^2) in f32 is within the margin m of the real-valued position of |X|^2 on the index
             // scale (sp_host.cpp); a and the clamp bounds are lowered by m, so floor(t) is exact unless fract(t) >= 1 - 2m.
@@ -867,14 +685,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
             // four independent min / max chains: a dependent f64 operation waits several issue slots
             double mn4[4] = {spjs::inf(), spjs::inf(), spjs::inf(), spjs::inf()}, mx4[4] = {0.0, 0.0, 0.0, 0.0};
             uint32_t *trow = (uint32_t *)(s_tile + fr * tile_pitch + tl * 16);
-#ifdef SP_ABL_NOEPI
-            asm volatile("" ::"v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(re[4]), "v"(re[5]), "v"(re[6]), "v"(re[7]), "v"(re[8]), "v"(re[9]), "v"(re[10]), "v"(re[11]), "v"(re[12]), "v"(re[13]), "v"(re[14]), "v"(re[15]));
-            asm volatile("" ::"v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(im[4]), "v"(im[5]), "v"(im[6]), "v"(im[7]), "v"(im[8]), "v"(im[9]), "v"(im[10]), "v"(im[11]), "v"(im[12]), "v"(im[13]), "v"(im[14]), "v"(im[15]));
-            if (false) {
-#else
             if (live) {
-#endif
-                constexpr int EB = SP_X_BATCH;   // bins per batch
+                constexpr int EB = 2;   // bins per batch
                 uint32_t tile_word = 0;          // four colour bytes per tile dword
                 // a batch of bins at a time: independent chains for the VALU, one branch per batch, four colour bytes per tile dword
 #pragma unroll
@@ -891,17 +703,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
 #pragma unroll
                     for (int k = 0; k < EB; k++) l2[k] = (float)abs2[k];
 #pragma unroll
-#ifndef SP_ABL_NOLOG
                     for (int k = 0; k < EB; k++) l2[k] = __log2f(l2[k]);
-#else
-                    for (int k = 0; k < EB; k++) l2[k] = l2[k] * 3.0f;
-#endif
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
-#ifndef SP_ABL_NOMM
                         mn4[k & 3] = min_raw(mn4[k & 3], abs2[k]);
                         mx4[k & 3] = max_raw(mx4[k & 3], abs2[k]);
-#endif
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
@@ -920,20 +726,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
-#ifndef SP_ABL_NORISKY
                         // (the clamps have turned a NaN into a bound, so the fractional parts are numbers; one threshold, the
                         // smaller of the two, serves both scales)
                         worst = fmaxf(fmaxf(worst, __builtin_amdgcn_fractf(tg[k])), __builtin_amdgcn_fractf(tc[k]));   // one v_max3_f32
-#endif
                         cell[k] += gi[k];
                     }
                     if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
 #pragma unroll
                         for (int k = 0; k < EB; k++)
                             risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < thr) || !(__builtin_amdgcn_fractf(tc[k]) < thr);
-#ifdef SP_STAMPS
-                        stamp_slow++;
-#endif
                         // nearest edge on either scale for every lane (one batch of reads, one wait), then one exact comparison
                         // each; only the risky lanes keep the result (edges: sp_host.h Thresholds)
                         int rg[EB], rc[EB];
@@ -960,21 +761,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                             cell[k] = risky[k] ? c : cell[k];
                         }
                     }
-#ifndef SP_ABL_NOTILE
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
                         const int e = EB * q + k;                 // compile-time after unrolling
                         tile_word = (e & 3) == 0 ? (uint32_t)gi[k] : tile_word | ((uint32_t)gi[k] << (8 * (e & 3)));
                         if ((e & 3) == 3) trow[e >> 2] = tile_word;
                     }
-#endif
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
-#ifndef SP_ABL_NOHIST
                         atomicAdd(&s_cells[cell[k]], 1u);
-#else
-                        asm volatile("" ::"v"(cell[k]));
-#endif
                     }
                 }
                 const double mn = min_raw(min_raw(mn4[0], mn4[1]), min_raw(mn4[2], mn4[3]));
@@ -983,29 +778,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
                 atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
-            SP_STAMP(5)   // epilogue
         }
         drain_x0 = x0;
     }
 
-#ifdef SP_STAMPS
-    unsigned long long tail_stamp[4] = {0, 0, 0, 0};
-    {
-        const unsigned long long loop_end = clock64();
-        if (lane == 0 && a.scratch) {
-            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 20;
-            for (int k = 0; k < 6; k++) dst[k] = stamp_sum[k];
-            dst[6] = loop_end - stamp_begin;
-            dst[7] = stamp_slow;
-            dst[8] = stamp_begin - stamp_entry;   // prologue
-            dst[16] = pro_stamp[0] - stamp_entry;
-            dst[17] = pro_stamp[1] - pro_stamp[0];
-            dst[18] = stamp_begin - pro_stamp[1];
-            dst[19] = meet.spent;
-            dst[15] = loop_end;
-        }
-    }
-#endif
     // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
     if (HALVES && drain_x0 >= 0 && a.rgba) {
         // The workgroup's last write-out overlaps nothing.  The first waves of the SIMDs reach it ~7 us before the second ones (config 2;
@@ -1021,20 +797,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
         drain_rows(drain_x0, 0, 1, half * (group_frames / 2), group_frames / 2, half * (kThreads / 2), kThreads / 2, false, true);
     }
     lds_barrier();
-    SP_TAIL_STAMP(0)
     for (int i = tid; i < a.cells; i += kThreads) {
         const unsigned int v = s_cells[i];
         // one copy per XCD (workgroups b and b + 8 share one): 32 adders per word instead of 256
         if (v) atomicAdd(&a.cell_acc[(size_t)xcd * a.cells_cap + i], (unsigned long long)v);
     }
-    SP_TAIL_STAMP(1)
     if (drain_x0 >= 0) {
         if (HALVES && a.rgba) drain_rows(drain_x0, 0, 1, 0, 0, 0, kThreads, true, false);   // the extremes only
         else drain(drain_x0, 0, 1);
-        SP_TAIL_STAMP(2)
         lds_barrier();
     }
-    SP_TAIL_STAMP(3)
     if (tid < group_frames) {
         if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
         if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
@@ -1044,42 +816,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void k_frames(const
         if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
         if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
     }
-#ifdef SP_STAMPS
-    {
-        unsigned long long t_end, rt_end;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end) :: "memory");
-        if (lane == 0 && a.scratch) {
-            unsigned long long *dst = (unsigned long long *)a.scratch + ((size_t)blockIdx.x * WAVES + (tid >> 6)) * 20;
-            dst[9] = t_end - stamp_entry;          // whole wave, shader clock
-            dst[10] = rt_end - stamp_entry_rt;     // whole wave, constant 100 MHz clock
-            dst[11] = stamp_entry_rt;              // start time (spread of the launch over the workgroups)
-            const unsigned long long le = dst[15];
-            dst[12] = tail_stamp[0] - le;            // wait at the barrier after the loop
-            unsigned hw_id;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-            dst[13] = hw_id;                         // wave slot [3:0], SIMD [5:4], CU [11:8], SE [15:13]
-            dst[14] = tail_stamp[2] - tail_stamp[1]; // last write-out issued
-            dst[15] = t_end - tail_stamp[2];         // barrier, extremes, outstanding stores and atomics
-        }
-    }
-#endif
 }
 
-// Waves per workgroup (one workgroup per CU): 8 = two per SIMD with the edge tables in LDS; 12 = three per SIMD (<= 168 VGPRs,
-// edge tables read from L2 by the rare lanes that need them, 24-frame groups) for the sizes whose frames fit a wave.
-#ifndef SP_FRAMES_WAVES
-#define SP_FRAMES_WAVES 8
-#endif
-#ifndef SP_X_EDGES_GLOBAL
-#define SP_X_EDGES_GLOBAL 0
-#endif
-__host__ __device__ inline constexpr int frames_waves(int log2n, bool channel_mode, int prefetch)
-{
-    if (SP_FRAMES_WAVES == 4) return (log2n == 10 && !channel_mode && prefetch != 0) ? 4 : 8;
-    return (log2n == 10 && !channel_mode && (prefetch == 8 || prefetch == 4 || prefetch == 2 || prefetch == 1)) ? SP_FRAMES_WAVES : 8;
-}
-
-// Per-n launchers, one translation unit each (sp_inst_frames.hip compiled once per LOG2N).
+// Per-n launchers, one translation unit each (sp_inst_frames.hip is compiled once per LOG2N).
 template <int L>
 int launch_frames_n(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int prefetch,
                     int device, hipStream_t stream);
@@ -1091,30 +830,18 @@ SP_DECL(6) SP_DECL(7) SP_DECL(8) SP_DECL(9) SP_DECL(10) SP_DECL(11) SP_DECL(12) 
 
 #ifdef SP_INST_FRAMES_LOG2N
 // per-device, per-variant opt-in to the full LDS (function attributes belong to the device's code object)
-template <int L, bool C, int P, int W, bool E>
+template <int L, bool C, int P>
 inline int launch_variant(const FrameArgs &a, int format, const double2 *stage_tw, int grid, int lds_bytes, int gf, int groups, int device,
                           hipStream_t stream)
 {
-    static bool attr_set[kMaxDevices] = {};
-    if (device < 0 || device >= kMaxDevices || !attr_set[device]) {
-        if (hipFuncSetAttribute((const void *)k_frames<L, C, P, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    // (contexts of several devices render on different threads: the flags are atomic, and setting the attribute twice is harmless)
+    static std::atomic<bool> attr_set[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices || !attr_set[device].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void *)k_frames<L, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SP_ERR_HIP;
-        if (device >= 0 && device < kMaxDevices) attr_set[device] = true;
+        if (device >= 0 && device < kMaxDevices) attr_set[device].store(true, std::memory_order_release);
     }
-#ifdef SP_DEBUG_OCC
-    {
-        static bool once = false;
-        if (!once) {
-            once = true;
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_frames<L, C, P, W, E>, W * 64, (size_t)lds_bytes);
-            fprintf(stderr, "k_frames<%d,%d,%d,%d,%d>: %d blocks per CU at %d bytes of LDS, grid %d, group %d frames\n", L, (int)C, P, W, (int)E, nb,
-                    lds_bytes, grid, gf);
-        }
-    }
-#endif
-    hipLaunchKernelGGL((k_frames<L, C, P, W, E>), dim3((unsigned)grid), dim3(W * 64), (size_t)lds_bytes, stream, a, format, stage_tw, gf,
-                       groups);
+    hipLaunchKernelGGL((k_frames<L, C, P>), dim3((unsigned)grid), dim3(kFrameThreads), (size_t)lds_bytes, stream, a, format, stage_tw, gf, groups);
     return SP_OK;
 }
 
@@ -1123,7 +850,7 @@ int launch_frames_n<SP_INST_FRAMES_LOG2N>(const FrameArgs &a, int format, const 
                                    int prefetch, int device, hipStream_t stream)
 {
     constexpr int L = SP_INST_FRAMES_LOG2N;
-#define SP_V(C, P) return launch_variant<L, C, P, frames_waves(L, C, P), frames_waves(L, C, P) == 8 && !SP_X_EDGES_GLOBAL>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
+#define SP_V(C, P) return launch_variant<L, C, P>(a, format, stage_tw, grid, lds_bytes, gf, groups, device, stream);
 #define SP_CH(C)                                                                                              \
     switch (prefetch) {                                                                                       \
     case 8: SP_V(C, 8) case 4: SP_V(C, 4) case 3: SP_V(C, 3) case 2: SP_V(C, 2) case 1: SP_V(C, 1) default: SP_V(C, 0) \
@@ -1139,23 +866,15 @@ inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw
 {
     int prefetch = (a.in_bounds && (a.sample_width <= 4 || a.sample_width == 8)) ? a.sample_width : 0;
     if (prefetch == 3 && !(a.width >= 2 && frame_start(a.stride, a.width - 1) >= 1)) prefetch = 0;
-    const int waves = frames_waves(a.levels, a.channel_mode != 0, prefetch);
-    if (!frames_kernel_supports(a.n, waves) || a.lut_len > kLdsMaxLut || a.lut_len < 2) return SP_ERR_UNSUPPORTED;
+    if (!frames_kernel_supports(a.n) || a.lut_len > kLdsMaxLut || a.lut_len < 2) return SP_ERR_UNSUPPORTED;
     const int n = a.n;
-#ifndef SP_X_WANT
-#define SP_X_WANT 32
-#endif
-    int want = SP_X_WANT;
+    int want = 32;
     while (want > 4 && (a.x_end - a.frame0 + want - 1) / want < 2 * cu_count) want >>= 1;
-    // (12 waves at n = 1024: 32-frame groups in three rounds, the last one with 8 of the 12 slots;
-    //  4 waves: two workgroups per CU, 80 KiB of LDS each: 16-frame groups)
-    if (waves == 4 && want > 16) want = 16;
-    const int wg_per_cu = waves == 4 ? 2 : 1;
-    const int gf = waves > 8 && want >= 32 ? 32 : group_frames_for(n, want, waves * 64);
+    const int gf = group_frames_for(n, want);
     const int groups = (a.x_end - a.frame0 + gf - 1) / gf;
-    const Layout lay = layout(n, a.lut_len, gf, waves * 64, waves == 8 && !SP_X_EDGES_GLOBAL, waves == 8);
-    if (lay.total > 160 * 1024 / wg_per_cu) return SP_ERR_UNSUPPORTED;
-    int grid = groups < cu_count * wg_per_cu ? groups : cu_count * wg_per_cu;
+    const Layout lay = layout(n, a.lut_len, gf);
+    if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;
+    int grid = groups < cu_count ? groups : cu_count;
     grid = (grid + 7) & ~7;
     switch (a.levels) {
 #define SP_L(L) case L: return launch_frames_n<L>(a, format, stage_tw, grid, lay.total, gf, groups, prefetch, device, stream);

@@ -82,7 +82,7 @@ def test_golden_worker_cases_sp_render(pkg, ctx, golden):
     assert not bad, bad[:30]
 
 
-@pytest.mark.parametrize("kernel", ["scratch", "lds", "frames"])
+@pytest.mark.parametrize("kernel", ["scratch", "frames"])
 def test_golden_worker_cases_each_kernel(pkg, ctx, golden, kernel):
     """The same vectors through sp_plan_execute with each device kernel forced (device-resident operands)."""
     bad, ran = [], 0
@@ -370,9 +370,9 @@ def test_pixels_straddling_every_index_edge(pkg, ctx):
     i = np.arange(L)
     lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
     want = pyoracle.render(fmt, data, n, win, block_norm, gain, rng, lut, W)
-    for kernel in ("frames", "lds", "scratch"):
+    for kernel in ("frames", "scratch"):
         got = _plan_render(pkg, ctx, kernel, fmt, data, n, win, block_norm, gain, rng, lut, W, False, False)
-        assert got is not None and got["kernel"] == {"frames": "frames", "lds": "lds_r16", "scratch": "scratch_radix2"}[kernel]
+        assert got is not None and got["kernel"] == {"frames": "frames", "scratch": "scratch_radix2"}[kernel]
         assert np.array_equal(got["rgba"], want["rgba"]), kernel
         assert np.array_equal(got["c_hist"].astype(np.int64), want["c_hist"]), kernel
         assert np.array_equal(got["cB_hist"].astype(np.int64), want["cB_hist"]), kernel
@@ -480,7 +480,7 @@ def test_reply_is_overwritten_not_accumulated(pkg, ctx):
     i = np.arange(256)
     lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
     want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, W)
-    for kernel in ("frames", "lds", "scratch"):
+    for kernel in ("frames", "scratch"):
         plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
         plan.force_kernel(kernel)
         d_in = ctx.alloc(data.size)

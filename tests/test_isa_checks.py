@@ -1,0 +1,57 @@
+"""Checks on the compiled gfx950 code objects (no GPU needed: hipcc cross-compiles, llvm-objdump disassembles).
+
+The re-distributions of the frame loop read LDS with inline-asm ds_read_b64 instructions whose wait comes later, in a separate asm
+statement (sp_frame_parts.h); the compiler does not know the destination registers are invalid in between.  tools/check_lds_reads.py
+follows the in-order LDS counter through every kernel of the product and fails on any access to a register with an outstanding read."""
+import glob
+import importlib.util
+import os
+
+from __graft_entry__ import ROOT, build
+
+
+def _checker():
+    spec = importlib.util.spec_from_file_location("check_lds_reads", os.path.join(ROOT, "tools", "check_lds_reads.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_checker_sees_a_register_touched_before_its_read_has_returned():
+    c = _checker()
+    ok = """
+0000000000001000 <k>:
+	ds_write_b64 v10, v[2:3]                                   // 000000001000: D89A0000 0000020A
+	ds_read_b64 v[2:3], v11 offset:8                           // 000000001008: D8EC0008 0200000B
+	ds_read_b64 v[4:5], v11 offset:16                          // 000000001010: D8EC0010 0400000B
+	v_add_f64 v[6:7], v[8:9], v[8:9]                           // 000000001018: D2800006 00021108
+	s_waitcnt lgkmcnt(1)                                       // 000000001020: BF8CC17F
+	v_mul_f64 v[2:3], v[2:3], v[8:9]                           // 000000001024: D2810002 00021102
+	s_waitcnt lgkmcnt(0)                                       // 00000000102C: BF8CC07F
+	v_mul_f64 v[4:5], v[4:5], v[8:9]                           // 000000001030: D2810004 00021104
+	s_endpgm                                                   // 000000001038: BF810000
+""".split("\n")
+    assert c.check_listing(ok) == []
+    copied_early = [ln.replace("v_add_f64 v[6:7], v[8:9], v[8:9]", "v_mov_b32_e32 v20, v4") for ln in ok]        # a copy before the wait
+    assert len(c.check_listing(copied_early)) == 1
+    clobbered = [ln.replace("v_add_f64 v[6:7], v[8:9], v[8:9]", "v_add_f64 v[2:3], v[8:9], v[8:9]") for ln in ok]   # a write under the read
+    assert len(c.check_listing(clobbered)) == 1
+    short_wait = [ln.replace("s_waitcnt lgkmcnt(1)", "s_waitcnt lgkmcnt(2)") for ln in ok]                           # waits for nothing
+    assert len(c.check_listing(short_wait)) == 1
+
+
+def test_no_kernel_of_the_product_touches_a_register_with_an_outstanding_lds_read():
+    objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "*.o")))
+    if len(objs) < 9:
+        build()
+        objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "*.o")))
+    objs = [o for o in objs if not o.endswith("sp_host.o")]
+    assert len(objs) >= 9
+    c = _checker()
+    bad, reads = [], 0
+    for o in objs:
+        lines = c.disassemble(o)
+        reads += sum(1 for ln in lines if " ds_read_b64 " in ln.replace("\t", " "))
+        bad += c.check_listing(lines, os.path.basename(o))
+    assert reads > 5000            # the asm reads are there (16 per component and re-distribution in every variant)
+    assert not bad, bad[:10]

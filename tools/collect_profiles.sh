@@ -17,7 +17,7 @@ for C in $CFGS; do
   python3 - "$OUT/${TAG}_${C}_pmc_summary.txt" "$C" > $OUT/${TAG}_${C}_traffic.json <<'PY'
 import json, re, sys
 txt = open(sys.argv[1]).read()
-blk = [b for b in txt.split("== ") if "k_frames" in b or "k_lds_r16" in b or "k_scratch" in b]
+blk = [b for b in txt.split("== ") if "k_frames" in b or "k_scratch" in b]
 blk = max(blk, key=lambda b: float(re.search(r"SQ_WAVE_CYCLES\s+n=\s*\d+\s+mean=\s*([\d.]+)", b).group(1)) if "SQ_WAVE_CYCLES" in b else 0)
 name = blk.splitlines()[0]
 g = lambda k: float(re.search(k + r"\s+n=\s*\d+\s+mean=\s*([\d.]+)", blk).group(1))
@@ -33,7 +33,7 @@ PY
   python3 - "$OUT/${TAG}_${C}_pmc_summary.txt" "$C" > $OUT/${TAG}_${C}_valu.json <<'PY'
 import json, re, sys
 txt = open(sys.argv[1]).read()
-blk = [b for b in txt.split("== ") if "k_frames" in b or "k_lds_r16" in b or "k_scratch" in b]
+blk = [b for b in txt.split("== ") if "k_frames" in b or "k_scratch" in b]
 blk = max(blk, key=lambda b: float(re.search(r"SQ_WAVE_CYCLES\s+n=\s*\d+\s+mean=\s*([\d.]+)", b).group(1)) if "SQ_WAVE_CYCLES" in b else 0)
 def g(k):
     m = re.search(k + r"\s+n=\s*\d+\s+mean=\s*([\d.]+)", blk)

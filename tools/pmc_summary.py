@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
         for row in csv.DictReader(fh):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
-    if not any(s in k for s in ("k_lds", "k_scratch", "k_frames", "k_finish")):
+    if not any(s in k for s in ("k_scratch", "k_frames", "k_finish")):
         continue
     print("== %s" % k[:110])
     for c in sorted(acc[k]):
