@@ -5,13 +5,16 @@
  * (lib/spectroplot.js:1096-1285) without a browser:
  *
  *   node spectroplot-js_amd/js/cli.js capture_433.92M_250k.cu8 --n 1024 --width 2048 [--format cu8] [--window blackmanHarris]
- *        [--cmap cube1|viridis|plasma|inferno|magma|hot|afmhot|gist_heat|sox|naive|grayscale|roentgen|phosphor|parabola] [--gain 6] [--range 30] [--workers N] [--waterfall] [--lr] --out image.ppm
+ *        [--cmap cube1|viridis|plasma|inferno|magma|hot|afmhot|gist_heat|sox|naive|grayscale|roentgen|phosphor|parabola] [--gain 6] [--range 30] [--workers N] [--waterfall] [--lr]
+ *        [--full] --out image.ppm
  *
  * The format defaults to the file extension (lib/parseFreqRate.js:58-70), the worker count to the number of visible GPUs.
  * Output: binary PPM (P6, alpha dropped) or, with --out *.rgba, the raw RGBA bytes exactly as the reference's canvas holds them.
+ * --full composes the plot the reference shows around the spectrogram as far as it can be drawn exactly (js/raster.js): amplitude and
+ * min/max gauge strips above it, the dB scale (colour ramp, tick marks) to its right; labels and histogram outlines need a canvas.
  */
 const fs = require('fs')
-const { renderSliced, parseFormat, parseFreqRate, HipWorker } = require('./index.js')
+const { renderSliced, parseFormat, parseFreqRate, HipWorker, composePlot, cmapByName } = require('./index.js')
 
 function main(argv) {
     const opt = { n: 512, width: 1024, window: 'blackmanHarris', cmap: 'cube1', gain: 6, range: 30, out: 'spectrogram.ppm' }
@@ -19,6 +22,7 @@ function main(argv) {
     for (let i = 0; i < argv.length; i++) {
         const a = argv[i]
         if (a === '--waterfall') opt.waterfall = true
+        else if (a === '--full') opt.full = true
         else if (a === '--lr') opt.channelMode = true
         else if (a.startsWith('--')) opt[a.slice(2)] = argv[++i]
         else file = a
@@ -34,7 +38,14 @@ function main(argv) {
         // the option names travel as they are: the library resolves them as the reference's caller does (sp_render_named)
         byName: true, window: String(opt.window), cmap: String(opt.cmap), gain: parseFloat(opt.gain), range: parseFloat(opt.range), channelMode: !!opt.channelMode, waterfall: !!opt.waterfall })
         .then(img => {
-            if (opt.out.endsWith('.rgba')) {
+            if (opt.full) {
+                const cmap = cmapByName(String(opt.cmap)).map(c => c.slice())
+                cmap[0] = [0, 0, 0]; cmap[cmap.length - 1] = [255, 255, 255]                    // lib/spectroplot.js:1129-1130
+                const plot = composePlot(img, { cmap, gain: parseFloat(opt.gain), range: parseFloat(opt.range), n, waterfall: !!opt.waterfall })
+                if (opt.out.endsWith('.rgba')) fs.writeFileSync(opt.out, Buffer.from(plot.surface.data.buffer))
+                else fs.writeFileSync(opt.out, plot.surface.toPPM())
+                img = { width: plot.surface.width, height: plot.surface.height, dBfs_min: img.dBfs_min, dBfs_max: img.dBfs_max }
+            } else if (opt.out.endsWith('.rgba')) {
                 fs.writeFileSync(opt.out, Buffer.from(img.data.buffer))
             } else {
                 const rgb = Buffer.alloc(img.width * img.height * 3)

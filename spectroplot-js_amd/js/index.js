@@ -4,4 +4,5 @@ const { HipWorker, packLut } = require('./hip_worker.js')
 const { renderSliced, stripPlacement } = require('./render_file.js')
 const params = require('./params.js')
 const consumers = require('./consumers.js')
-module.exports = Object.assign({ HipWorker, packLut, renderSliced, stripPlacement }, params, consumers)
+const raster = require('./raster.js')
+module.exports = Object.assign({ HipWorker, packLut, renderSliced, stripPlacement }, params, consumers, raster)

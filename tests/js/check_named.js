@@ -58,6 +58,17 @@ async function main() {
     if (p.slice(0, header.length).toString() !== header || p.length !== header.length + 3 * 2048 * 512) failures.push('cli.js: PPM header / size')
     const rgba = fs.readFileSync(out1)
     for (const px of [0, 12345, 2048 * 512 - 1]) for (let k = 0; k < 3; k++) if (p[header.length + 3 * px + k] !== rgba[4 * px + k]) { failures.push('cli.js: PPM pixel ' + px); break }
+    // --full: gauges above, dB scale to the right; the spectrogram sits at composePlot's image origin, untouched
+    const full = path.join(dir, 'full.rgba')
+    const flog = execFileSync('node', [cli, capture, '--n', '512', '--width', '2048', '--window', 'hann', '--workers', '1', '--full', '--out', full]).toString()
+    const fm = /\((\d+) x (\d+)\)/.exec(flog)
+    const FW = +fm[1], FH = +fm[2], fb = fs.readFileSync(full)
+    if (FW !== 2048 + 160 || FH !== 64 + 532 || fb.length !== 4 * FW * FH) failures.push(`cli.js --full: size ${FW} x ${FH}`)
+    else {
+        for (const [x, y] of [[0, 0], [1000, 300], [2047, 511]]) for (let k = 0; k < 4; k++)
+            if (fb[4 * ((y + 64) * FW + x) + k] !== rgba[4 * (y * 2048 + x) + k]) { failures.push(`cli.js --full: image pixel ${x},${y}`); break }
+        if (fb[4 * ((64 + 10) * FW + 2048 + 35) + 3] !== 255) failures.push('cli.js --full: colour ramp missing')
+    }
     fs.rmdirSync(dir, { recursive: true })
 
     if (failures.length) { console.log(failures.join('\n')); process.exit(1) }

@@ -37,6 +37,14 @@ def test_side_output_consumers_match_reference_draw_calls():
     assert "consumers checks ok" in out.stdout
 
 
+def test_software_rasteriser_replays_the_references_gauge_and_ramp_calls():
+    """js/raster.js: the reference's recorded gauge rectangles and colour-ramp calls replayed on the software surface, pixel for pixel
+    against a per-pixel model; composePlot's layout."""
+    out = _node("check_raster.js")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "raster checks ok" in out.stdout
+
+
 def test_slice_merge_and_gauges_reproduce_the_references_own_caller():
     """renderSliced / stripPlacement / gaugeColumns against what the reference's startWorkers + processData did with 1, 2 and 8
     workers (tests/golden/caller.json), the workers being the JavaScript oracle here."""
