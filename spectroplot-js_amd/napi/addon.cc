@@ -10,7 +10,8 @@
 //   parseFormat(name)                              -> {id, sampleWidth}
 //   window(name, n)                                -> {window: Float64Array, weight}
 //   sliceBounds(nbytes, sampleWidth, index, count) -> [begin, end]
-//   poolStats()                                    -> {fresh, recycled, recycledPinned, freeBytes} of the reply-image pool
+//   poolStats()                                    -> {fresh, recycled, recycledPinned, freeBytes, pinnedBytes, pinRefused, keepLimit,
+//                                                      pinnedLimit, replyWeightCap} of the reply-image pool
 //   cmap(name)                                     -> Uint8Array of r,g,b triples (the reference's map under its lookup rules) or null
 //   cmapKeys()                                     -> the reference's colour-map keys in its table order
 //   allocBuffer(nbytes)                            -> ArrayBuffer in page-locked host memory (sp_host_alloc): a request whose `buffer`
@@ -107,28 +108,51 @@ void ctx_release(Ctx *x)
 // holds (napi_adjust_external_memory), so dropped replies are collected under memory pressure like any large ArrayBuffer.
 // A block that comes round a second time is page-locked (on the worker thread, once): copies into it then run asynchronously at
 // the rate of the host link, which is what lets sp_render overlap the image's way back with the samples' way in.
+// Limits, each read once from the environment (MiB): SPECTROPLOT_HIP_POOL_KEEP_MB bounds the dropped blocks kept for reuse (default
+// 3072), SPECTROPLOT_HIP_POOL_PINNED_MB the page-locked bytes of pool blocks, free or held by JavaScript (default 1024; 0 = never
+// page-lock), SPECTROPLOT_HIP_REPLY_WEIGHT_MB what V8 is told a reply weighs at most (below).
+inline size_t env_mib(const char *name, size_t dflt_mib)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt_mib << 20;
+    char *end = nullptr;
+    const unsigned long long v = strtoull(e, &end, 10);
+    return (end && *end == 0) ? (size_t)v << 20 : dflt_mib << 20;
+}
+enum PinState : int { kUnpinned = 0, kPinned = 1, kPinRefused = 2 };   // kPinRefused: hipHostRegister failed for this block; not retried
 struct HostPool {
-    struct Block { void *p; size_t size; bool pinned; };
+    struct Block { void *p; size_t size; int pin; };
     std::mutex m;
     std::vector<Block> free_blocks;
-    size_t free_bytes = 0;
-    size_t n_fresh = 0, n_recycled = 0, n_recycled_pinned = 0;   // poolStats()
-    static constexpr size_t kKeepBytes = (size_t)3 << 30;
-    void *take(size_t size, bool *pinned)
+    size_t free_bytes = 0, pinned_bytes = 0;
+    size_t n_fresh = 0, n_recycled = 0, n_recycled_pinned = 0, n_pin_refused = 0;   // poolStats()
+    const size_t keep_bytes = env_mib("SPECTROPLOT_HIP_POOL_KEEP_MB", 3072);
+    const size_t pinned_limit = env_mib("SPECTROPLOT_HIP_POOL_PINNED_MB", 1024);
+    void *take(size_t size, int *pin)
     {
-        *pinned = false;
+        *pin = kUnpinned;
         {
             std::unique_lock<std::mutex> g(m);
             for (size_t i = 0; i < free_blocks.size(); i++)
                 if (free_blocks[i].size == size) {
                     void *p = free_blocks[i].p;
-                    *pinned = free_blocks[i].pinned;
+                    *pin = free_blocks[i].pin;
                     n_recycled++;
-                    if (*pinned) n_recycled_pinned++;
+                    if (*pin == kPinned) n_recycled_pinned++;
                     free_bytes -= size;
                     free_blocks.erase(free_blocks.begin() + (long)i);
+                    const bool try_pin = *pin == kUnpinned && size >= ((size_t)1 << 20) && pinned_bytes + size <= pinned_limit;
+                    if (try_pin) pinned_bytes += size;   // reserved under the lock, returned below if the registration fails
                     g.unlock();
-                    if (!*pinned && size >= ((size_t)1 << 20)) *pinned = sp_host_register(p, size) == SP_OK;
+                    if (try_pin) {
+                        if (sp_host_register(p, size) == SP_OK) *pin = kPinned;
+                        else {
+                            *pin = kPinRefused;
+                            std::lock_guard<std::mutex> g2(m);
+                            pinned_bytes -= size;
+                            n_pin_refused++;
+                        }
+                    }
                     return p;
                 }
         }
@@ -146,15 +170,18 @@ struct HostPool {
 #endif
         return p;
     }
-    void give(void *p, size_t size, bool pinned)
+    void give(void *p, size_t size, int pin)
     {
         std::lock_guard<std::mutex> g(m);
-        if (free_bytes + size > kKeepBytes) {
-            if (pinned) sp_host_unregister(p);
+        if (free_bytes + size > keep_bytes) {
+            if (pin == kPinned) {
+                sp_host_unregister(p);
+                pinned_bytes -= size;
+            }
             free(p);
             return;
         }
-        free_blocks.push_back({p, size, pinned});
+        free_blocks.push_back({p, size, pin});
         free_bytes += size;
     }
 };
@@ -164,15 +191,16 @@ HostPool g_pool;
 // external-memory limit by itself: one mark-sweep per message (1.2 ms each, `node --trace-gc tools/js_dropin_bench.js`).  Capped, the
 // collector runs about every fourth large reply - as it does for 16 MiB replies anyway - and the pool holds five or six blocks
 // instead of two; the blocks still return by collection only.
-constexpr size_t kReplyWeightCap = (size_t)16 << 20;
-inline int64_t reply_weight(size_t size) { return (int64_t)(size < kReplyWeightCap ? size : kReplyWeightCap); }
-struct PoolTag { size_t size; bool pinned; };
+// SPECTROPLOT_HIP_REPLY_WEIGHT_MB changes the cap (a caller that holds many replies at once can raise it to their real size).
+const size_t g_reply_weight_cap = env_mib("SPECTROPLOT_HIP_REPLY_WEIGHT_MB", 16);
+inline int64_t reply_weight(size_t size) { return (int64_t)(size < g_reply_weight_cap ? size : g_reply_weight_cap); }
+struct PoolTag { size_t size; int pin; };
 void pool_free_cb(napi_env env, void *data, void *hint)
 {
     PoolTag *t = (PoolTag *)hint;
     int64_t total = 0;
     napi_adjust_external_memory(env, -reply_weight(t->size), &total);
-    g_pool.give(data, t->size, t->pinned);
+    g_pool.give(data, t->size, t->pin);
     delete t;
 }
 
@@ -191,7 +219,7 @@ struct Job {
     // outputs: the image in a recycled block, the gauges malloc'd; handed to JS as external ArrayBuffers
     uint8_t *rgba = nullptr, *gmin = nullptr, *gmax = nullptr, *gamp = nullptr;
     size_t rgba_size = 0;
-    bool rgba_pinned = false;
+    int rgba_pin = kUnpinned;
     std::vector<uint64_t> c_hist, cb_hist;
     double minmax[2] = {0.0, -200.0};
     int status = SP_OK;
@@ -290,7 +318,7 @@ void run_job(Job *j)
 {
     const size_t W = j->width > 0 ? (size_t)j->width : 0, n = j->req.n > 0 ? (size_t)j->req.n : 0;
     j->rgba_size = 4 * W * n + 1;
-    j->rgba = (uint8_t *)g_pool.take(j->rgba_size, &j->rgba_pinned);
+    j->rgba = (uint8_t *)g_pool.take(j->rgba_size, &j->rgba_pin);
     j->gmin = (uint8_t *)calloc(W + 1, 1);
     j->gmax = (uint8_t *)calloc(W + 1, 1);
     j->gamp = (uint8_t *)calloc(W + 1, 1);
@@ -335,7 +363,7 @@ napi_value make_reply(napi_env env, Job *j)
     };
     {
         napi_value ab;
-        PoolTag *tag = new PoolTag{j->rgba_size, j->rgba_pinned};
+        PoolTag *tag = new PoolTag{j->rgba_size, j->rgba_pin};
         if (napi_create_external_arraybuffer(env, j->rgba, 4 * W * n, pool_free_cb, tag, &ab) == napi_ok) {
             int64_t total = 0;
             napi_adjust_external_memory(env, reply_weight(j->rgba_size), &total);
@@ -365,7 +393,7 @@ napi_value make_reply(napi_env env, Job *j)
 
 void free_job(napi_env env, Job *j)
 {
-    if (j->rgba) g_pool.give(j->rgba, j->rgba_size, j->rgba_pinned);
+    if (j->rgba) g_pool.give(j->rgba, j->rgba_size, j->rgba_pin);
     free(j->gmin); free(j->gmax); free(j->gamp);
     if (j->ctx_ref) napi_delete_reference(env, j->ctx_ref);
     if (j->cb_ref) napi_delete_reference(env, j->cb_ref);
@@ -610,6 +638,11 @@ napi_value PoolStats(napi_env env, napi_callback_info)
     napi_create_double(env, (double)g_pool.n_recycled, &v); napi_set_named_property(env, out, "recycled", v);
     napi_create_double(env, (double)g_pool.n_recycled_pinned, &v); napi_set_named_property(env, out, "recycledPinned", v);
     napi_create_double(env, (double)g_pool.free_bytes, &v); napi_set_named_property(env, out, "freeBytes", v);
+    napi_create_double(env, (double)g_pool.pinned_bytes, &v); napi_set_named_property(env, out, "pinnedBytes", v);
+    napi_create_double(env, (double)g_pool.n_pin_refused, &v); napi_set_named_property(env, out, "pinRefused", v);
+    napi_create_double(env, (double)g_pool.keep_bytes, &v); napi_set_named_property(env, out, "keepLimit", v);
+    napi_create_double(env, (double)g_pool.pinned_limit, &v); napi_set_named_property(env, out, "pinnedLimit", v);
+    napi_create_double(env, (double)g_reply_weight_cap, &v); napi_set_named_property(env, out, "replyWeightCap", v);
     return out;
 }
 

@@ -549,6 +549,32 @@ def test_three_byte_samples_to_the_last_byte(pkg, ctx, fmt, n, frames, extra):
         _assert_same(got, want)
 
 
+@pytest.mark.parametrize("fmt", ["CU64", "CS64", "CF64"])
+@pytest.mark.parametrize("n,frames", [(64, 300), (256, 150), (1024, 70), (2048, 40), (8192, 9)])
+def test_sixteen_byte_samples(pkg, ctx, fmt, n, frames):
+    """The 16-byte formats (the frame loop's generic loader: one 16-byte load per sample when the frame starts) at sizes of every
+    synchronisation regime, I/Q and L/R, hop = n / overlapping / sparse, with frames that are silent, and for cf64 frames that hold
+    infinities, NaNs and finite values from 2^1017 up."""
+    samples = n * frames
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 1234 + n, "step": 4099, "gshift": 9, "amp": 0.6, "namp": 0.02}, samples).copy()
+    assert data.size == 16 * samples
+    data[2 * n * 16:4 * n * 16] = 0
+    if fmt == "CF64":
+        v = data.view(np.float64)
+        per = 2 * n
+        v[5 * per + 3] = np.inf
+        v[6 * per + per - 1] = np.nan
+        v[7 * per + 10] = -2.0 ** 1018
+        v[8 * per:9 * per] = 1e200
+    win, weight = pyoracle.window("blackmanHarris", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    for width, ch in ((frames, False), (frames, True), (2 * frames - 1, False), (max(1, frames // 3), False)):
+        want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, ch)
+        got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, ch)
+        _assert_same(got, want)
+
+
 def test_full_size_repeatable(pkg, ctx):
     """Config 2 at full size, executed three times into separate buffers: every output byte identical between runs (a race
     between waves, tiles or accumulators would show up as a difference)."""

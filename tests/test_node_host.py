@@ -11,10 +11,11 @@ pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node not i
 ADDON = os.path.join(ROOT, "spectroplot-js_amd", "lib", "spectroplot_hip.node")
 
 
-def _node(script, *args, timeout=600):
+def _node(script, *args, timeout=600, node_flags=(), env=None):
     if not os.path.exists(ADDON):
         build()
-    return subprocess.run(["node", os.path.join(ROOT, "tests", "js", script)] + list(args), capture_output=True, text=True, timeout=timeout)
+    return subprocess.run(["node"] + list(node_flags) + [os.path.join(ROOT, "tests", "js", script)] + list(args), capture_output=True,
+                          text=True, timeout=timeout, env=None if env is None else dict(os.environ, **env))
 
 
 def test_addon_loads_and_host_helpers_match_reference_kats():
@@ -82,3 +83,14 @@ def test_config5_at_full_size_through_the_javascript_boundary():
     out = _node("check_config5_full.js", timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "config 5 at full size through renderSliced ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,env", [("default", {}), ("nopin", {"SPECTROPLOT_HIP_POOL_PINNED_MB": "0"}),
+                                      ("tight", {"SPECTROPLOT_HIP_POOL_PINNED_MB": "8", "SPECTROPLOT_HIP_POOL_KEEP_MB": "16"})])
+def test_reply_image_pool_keeps_to_its_limits(mode, env):
+    """The addon's pool of reply images: recycled blocks carry correct images, page-locked bytes and kept bytes stay below the limits
+    set through the environment."""
+    out = _node("check_pool.js", mode, node_flags=["--expose-gc"], env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "pool checks ok (%s)" % mode in out.stdout

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput over formats x FFT sizes on one GPU (device-resident operands, frame loop + finish kernel), to spot variants that fall off:
-   ps per butterfly = time / (frames * n/2 * log2 n).      python3 tools/sweep.py [log2 samples]"""
+   ps per butterfly = time / (frames * n/2 * log2 n).      python3 tools/sweep.py [log2 samples] [FMT,FMT,...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,9 @@ from __graft_entry__ import load_package
 pkg = load_package()
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 S = 1 << lg
-WIDTH = {"CU4": 1, "CU8": 2, "CS8": 2, "CU12": 3, "CS12": 3, "CU16": 4, "CS16": 4, "CF32": 8, "CS32": 8, "CF64": 16}
+WIDTH = {"CU4": 1, "CU8": 2, "CS8": 2, "CU12": 3, "CS12": 3, "CU16": 4, "CS16": 4, "CF32": 8, "CS32": 8, "CF64": 16, "CS64": 16}
+if len(sys.argv) > 2:
+    WIDTH = {f: WIDTH[f] for f in sys.argv[2].split(",")}
 ctx = pkg.Context(0)
 lut = bench.load_cmap("viridis")
 L = len(lut)
