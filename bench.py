@@ -37,6 +37,8 @@ CONFIGS = {
     # not BASELINE configs: the 8-byte formats at the larger sizes (tuning runs of those kernel variants)
     "cf32_2048": ("CF32", 26, 2048, "blackmanHarris", "viridis", None, "64 MSample cf32, N=2048, Blackman-Harris, Viridis (not a BASELINE config)"),
     "cf32_4096": ("CF32", 26, 4096, "blackmanHarris", "viridis", None, "64 MSample cf32, N=4096, Blackman-Harris, Viridis (not a BASELINE config)"),
+    # config 5 without its zoom (hop = n, every sample read once): calibrates the HBM read counter for the 3-byte loader
+    "cs12_8192": ("CS12", 26, 8192, "blackmanHarris", "cube1", None, "64 MSample cs12, N=8192, no zoom (not a BASELINE config)"),
 }
 SAMPLE_WIDTH = {"CU8": 2, "CF32": 8, "CS16": 4, "CS12": 3}
 

@@ -20,10 +20,12 @@ PASSES=(
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
  "GRBM_GUI_ACTIVE"
 )
+# PMC_ONLY="6 7 8": run just these passes (1-based)
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/pass$i.log 2>&1
+  if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
+  timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/pass$i.log 2>&1
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $ROOT/gpurun_out/pmc_${TAG}_summary.txt 2>&1
 cat $ROOT/gpurun_out/pmc_${TAG}_summary.txt
