@@ -14,17 +14,19 @@ S = 1 << lg
 WIDTH = {"CU4": 1, "CU8": 2, "CS8": 2, "CU12": 3, "CS12": 3, "CU16": 4, "CS16": 4, "CF32": 8, "CS32": 8, "CF64": 16, "CS64": 16}
 if len(sys.argv) > 2:
     WIDTH = {f: WIDTH[f] for f in sys.argv[2].split(",")}
+CH = os.environ.get("SWEEP_CH") == "1"          # L/R channel split (fft_nayuki.js:103-119) instead of I/Q
+LO = int(os.environ.get("SWEEP_LOG2N_MIN", "6"))
 ctx = pkg.Context(0)
 lut = bench.load_cmap("viridis")
 L = len(lut)
 print("%-5s" % "n" + "".join("%14s" % f for f in WIDTH))
-for ln in range(6, 14):
+for ln in range(LO, 14):
     n = 1 << ln
     row = "%-5d" % n
     for fmt, sw in WIDTH.items():
         W = S // n
         win, weight = pkg.window("hann", n)
-        plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut)
+        plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, CH)
         d_in = torch.empty(S * sw, dtype=torch.uint8, device="cuda")
         ctx.synth_trinoise(d_in.data_ptr(), fmt, 0, S, bench.GEN["seed"], bench.GEN["step"], bench.GEN["gshift"], bench.GEN["amp"], bench.GEN["namp"])
         rgba = torch.empty(4 * W * n, dtype=torch.uint8, device="cuda")
