@@ -162,11 +162,13 @@ struct FrameSyncDefault {
 // SECOND: the imaginary parts, which follow the real parts through the same buffer: the sync before their writes comes right after
 // the reads of the real parts (nothing to split); the sync before the writes of the real parts was announced after the previous
 // re-distribution's last reads.
-template <int WS_FROM, int WS_TO, bool BLOCK_SYNC, bool SECOND, class SYNC = FrameSyncDefault<BLOCK_SYNC>>
+// FIRST_WAIT = false: the positions this re-distribution writes were last read by the writing wave itself (the one before it was
+// wave-private, below), so the real parts' writes need not wait for anybody.
+template <int WS_FROM, int WS_TO, bool BLOCK_SYNC, bool SECOND, class SYNC = FrameSyncDefault<BLOCK_SYNC>, bool FIRST_WAIT = true>
 __device__ inline void exchange(double (&v)[16], double *from, const double *to, SYNC &&sync = SYNC())   // from / to alias: no __restrict__
 {
     if constexpr (SECOND) sync();   // previous readers are done with the buffer
-    else sync.wait();
+    else if constexpr (FIRST_WAIT) sync.wait();
 #pragma unroll
     for (int e = 0; e < 16; e++) from[win_off(e, WS_FROM)] = v[e];
     sync();

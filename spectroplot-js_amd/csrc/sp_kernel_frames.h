@@ -593,8 +593,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 double *const b0 = xbuf + pad_idx(win_pos(tl, 0, 0)), *const b1 = xbuf + pad_idx(win_pos(tl, 0, WS1));
                 PassTw<WS1, 5, STAGED ? 4 : E1, TWMAX> tw1;
                 if constexpr (!STAGED) load_pass_tw(tw1, tl, s_tw, tw);
-                exchange<0, WS1, BLOCK_SYNC, false>(re, b0, b1, meet);
-                exchange<0, WS1, BLOCK_SYNC, true>(im, b0, b1, meet);
+                // The first re-distribution never leaves a wave, whatever n: under window 0 as under window [4,8) the 64 threads of a
+                // wave hold exactly the positions [1024 w, 1024 w + 1023] of their frame.  So the waves of a frame (n >= 2048) only
+                // wait, before its first writes, for the partners' last reads of the frame before; between its writes and reads the
+                // LDS's in-order execution of a wave's operations is all that is needed, as at n <= 1024.
+                meet.wait();
+                exchange<0, WS1, false, false>(re, b0, b1);
+                exchange<0, WS1, false, true>(im, b0, b1);
                 exchange_wait(re, im);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1, TWMAX>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
@@ -610,7 +615,8 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         exchange_permlane<LOG2N>(re);
                         exchange_permlane<LOG2N>(im);
                     } else {
-                        exchange<WS1, WS2, BLOCK_SYNC, false>(re, b1, b2, meet);
+                        // (writes the positions the wave itself read last: no wait before them)
+                        exchange<WS1, WS2, BLOCK_SYNC, false, decltype(meet) &, false>(re, b1, b2, meet);
                         exchange<WS1, WS2, BLOCK_SYNC, true>(im, b1, b2, meet);
                         exchange_wait(re, im);
                     }
