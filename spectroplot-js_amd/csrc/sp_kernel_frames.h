@@ -263,6 +263,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     constexpr bool BLOCK_SYNC = T > 64;
     constexpr int TWMAX = frames_tw_max_stage(N);
     constexpr int NPASS = (LOG2N + 3) / 4;
+    constexpr bool PERMLANE_MID = LOG2N == 13;
     constexpr bool STAGED = PFB == 0;   // the generic loaders leave no registers for a whole pass's twiddles: read stage by stage
     // 8-byte samples at n >= 2048: a frame's samples are requested when it starts, not one frame ahead (the prefetch registers of
     // the next frame were what spilled there: cf32, n = 2048: 411 -> 358 us per 32 768 frames); its partner wave covers the latency
@@ -603,7 +604,27 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 exchange_wait(re, im);
                 if constexpr (STAGED) fft_pass_staged<WS1, 5, E1, TWMAX>(re, im, tl, s_tw, tw);
                 else fft_pass<WS1, 5, E1>(re, im, tw1);
-                if constexpr (NPASS >= 3) {
+                if constexpr (PERMLANE_MID) {
+                    // n = 8192: the second re-distribution stays inside the wave too - the register transpose of the 1024-point
+                    // layout (window [4,8) -> [6,10) of the wave's block), two stages there, and only then the one re-distribution
+                    // that crosses waves, to window [9,13) for the last three stages.  Four workgroup barriers per frame instead of
+                    // eight; the swaps cost the VALU, which has the time at this size.
+                    PassTw<6, 9, STAGED ? 8 : 10, TWMAX> tw2;
+                    if constexpr (!STAGED) load_pass_tw(tw2, tl, s_tw, tw);
+                    exchange_permlane<10>(re);
+                    exchange_permlane<10>(im);
+                    if constexpr (STAGED) fft_pass_staged<6, 9, 10, TWMAX>(re, im, tl, s_tw, tw);
+                    else fft_pass<6, 9, 10>(re, im, tw2);
+                    constexpr int WS3 = LOG2N - 4;
+                    double *const b2 = xbuf + pad_idx(win_pos(tl, 0, 6)), *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
+                    PassTw<WS3, 11, STAGED ? 10 : LOG2N, TWMAX> tw3;
+                    if constexpr (!STAGED) load_pass_tw(tw3, tl, s_tw, tw);
+                    exchange<6, WS3, BLOCK_SYNC, false, decltype(meet) &, false>(re, b2, b3, meet);
+                    exchange<6, WS3, BLOCK_SYNC, true>(im, b2, b3, meet);
+                    exchange_wait(re, im);
+                    if constexpr (STAGED) fft_pass_staged<WS3, 11, LOG2N, TWMAX>(re, im, tl, s_tw, tw);
+                    else fft_pass<WS3, 11, LOG2N>(re, im, tw3);
+                } else if constexpr (NPASS >= 3) {
                     constexpr int WS2 = LOG2N >= 12 ? 8 : LOG2N - 4;
                     constexpr int E2 = LOG2N >= 12 ? 12 : LOG2N;
                     double *const b2 = xbuf + pad_idx(win_pos(tl, 0, WS2));
