@@ -230,6 +230,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
             // up its 8 consecutive cells from LDS
             // (every load of the thread is issued before the first sum: one memory latency instead of one per 256 cells)
             constexpr int kCopies = 8;
+            // (the cell ranges of this thread's two outputs ride in the same batch: read after the scan they were a second latency)
+            const int gi_c = gi < a.lut_len ? gi : 0, l_cb = gi < SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE - 1 - gi : 0;   // bin gi counts level 999 - gi
+            const int g_lo = a.cell_g[gi_c], g_hi = a.cell_g[gi_c + 1], l_lo = a.cell_l[l_cb], l_hi = a.cell_l[l_cb + 1];
             unsigned long long part[kPer][kCopies];
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
@@ -275,12 +278,8 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
             __syncthreads();
             const int sp0 = a.cells - 2, sp1 = a.cells - 1;
             const unsigned long long n0 = s_pre[sp0 + 1] - s_pre[sp0], n1 = s_pre[sp1 + 1] - s_pre[sp1];
-            if (gi < a.lut_len && a.out_c)
-                a.out_c[gi] = s_pre[a.cell_g[gi + 1]] - s_pre[a.cell_g[gi]] + (gi == 0 ? n0 : 0ull) + (gi == a.lut_len - 1 ? n1 : 0ull);
-            if (gi < SP_CB_HIST_SIZE && a.out_cb) {
-                const int l = SP_CB_HIST_SIZE - 1 - gi;                   // bin gi counts level 999 - gi
-                a.out_cb[gi] = s_pre[a.cell_l[l + 1]] - s_pre[a.cell_l[l]] + (gi == 0 ? n0 + n1 : 0ull);
-            }
+            if (gi < a.lut_len && a.out_c) a.out_c[gi] = s_pre[g_hi] - s_pre[g_lo] + (gi == 0 ? n0 : 0ull) + (gi == a.lut_len - 1 ? n1 : 0ull);
+            if (gi < SP_CB_HIST_SIZE && a.out_cb) a.out_cb[gi] = s_pre[l_hi] - s_pre[l_lo] + (gi == 0 ? n0 + n1 : 0ull);
         }
         if (gi < a.cells_cap * a.cell_copies) a.cell_clear[gi] = 0ull;   // the whole buffer: the next plan may use more cells than this one
     } else {
