@@ -602,6 +602,40 @@ def test_full_size_repeatable(pkg, ctx):
     plan.close()
 
 
+@pytest.mark.parametrize("fmt,n,lg,ch", [("CS16", 2048, 24, False), ("CF32", 2048, 23, True), ("CU8", 4096, 24, False), ("CF32", 4096, 23, False),
+                                         ("CS12", 8192, 24, False), ("CF32", 8192, 23, True)])
+def test_frames_shared_by_several_waves_are_race_free(pkg, ctx, fmt, n, lg, ch):
+    """n >= 2048: a frame's waves meet around the one re-distribution that crosses them and nowhere else (the first one - and at
+    n = 8192 the second - stays inside a wave).  A launch that keeps every CU busy for dozens of groups, four times over, must give the
+    same bytes every time, and the bytes of the portable kernel, which shares none of that synchronisation."""
+    S = 1 << lg
+    W = S // n
+    sw = siggen.SAMPLE_WIDTH[fmt]
+    win, weight = pyoracle.window("hann", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    d_in = ctx.alloc(S * sw)
+    ctx.synth_trinoise(d_in, fmt, 0, S, 0x5EED0002, 7321, 11, 0.5, 0.02)
+    sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+    runs = []
+    for kernel in ("scratch", "frames", "frames", "frames", "frames"):
+        plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, ch)
+        plan.force_kernel(kernel)
+        ptrs = [ctx.alloc(s) for s in sizes]
+        plan.execute(d_in, S * sw, W, *ptrs)
+        ctx.synchronize()
+        assert plan.kernel_name() == ("scratch_radix2" if kernel == "scratch" else "frames")
+        runs.append([ctx.download(p, s) for p, s in zip(ptrs, sizes)])
+        for p in ptrs:
+            ctx.free(p)
+        plan.close()
+    names = ["rgba", "gauge_mins", "gauge_maxs", "gauge_amps", "c_hist", "cB_hist", "dBfs"]
+    for k, r in enumerate(runs[1:]):
+        for name, a, b in zip(names, runs[0], r):
+            assert np.array_equal(a, b), (name, k)
+    ctx.free(d_in)
+
+
 def test_requests_by_name_match_the_golden_vectors_and_reuse_their_plan(pkg, golden):
     """sp_render_named: the request given as option names, resolved inside the library with the reference's lookup rules and defaults
     (lib/utils.js:25-40, lib/spectroplot.js:238-264, 1113-1146; the keys are the ones tests/golden/parse.json recorded from the reference).
