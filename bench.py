@@ -321,6 +321,20 @@ def main():
     # while the shader clock ramps, so a short --warmup would time the ramp instead of the kernel.
     # A fixed count (every rank runs the same collectives): ~0.3 s at config 2, scaled down for the larger configs.
     spinup = 0 if args.warmup >= 1000 else max(50, int(3000 * 16384 / max(W, 16384) * 1024 / n) if n <= 1024 else 200)
+    # what a caller sees before any of that (reported, never the headline): the very first step of this process (kernel code upload,
+    # cold caches, idle clocks) and the 20 steps right after it
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    step()
+    finish_pending()
+    torch.cuda.synchronize()
+    first_step_ms = (time.perf_counter() - tc) * 1e3
+    tc = time.perf_counter()
+    for _ in range(20):
+        step()
+    finish_pending()
+    torch.cuda.synchronize()
+    cold = {"first_step_ms": first_step_ms, "ms_per_step_next_20": (time.perf_counter() - tc) * 1e3 / 20}
     for _ in range(spinup):
         step()
     finish_pending()
@@ -415,7 +429,7 @@ def main():
             "metric": "STFT frames/sec (N=1024 cf32) + IQ MSamples/s end-to-end to RGBA" if args.config == "cfg2"
                       else "STFT frames/sec (%s)" % desc,
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "spinup_steps_untimed": spinup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "spinup_steps_untimed": spinup, "cold": cold, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W, "format": fmt, "n": n,
                        "samples_per_gpu": S, "frames_per_gpu": W, "window": window, "cmap": cmap,

@@ -732,12 +732,6 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
 
     if (ctx->timing) SP_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (which == 3) {
-#ifdef SP_STAMPS
-        // diagnostic build: per-wave phase clocks (tools/stamps.py reads them with sp_debug_read_stamps)
-        rc = ctx->scratch.reserve(4096 * 16 * 8 * sizeof(unsigned long long));
-        if (rc) return fail(ctx, rc, "stamps: out of device memory");
-        a.scratch = (double *)ctx->scratch.p;
-#endif
         rc = spk2::launch_frames(a, plan->req.format, plan->d_stage_tw, ctx->cu_count, ctx->device, s);
         if (rc) return fail(ctx, rc, "k_frames launch rejected the configuration");
     } else {
@@ -750,7 +744,8 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         if (rc) return fail(ctx, rc, "scratch: out of device memory");
         a.scratch = (double *)ctx->scratch.p;
         rc = dispatch_format(plan->req.format, [&](auto F) {
-            hipLaunchKernelGGL(spk::k_scratch_radix2<decltype(F)::value>, dim3((unsigned)blocks), dim3(spk::kScratchThreads), 0, s, a);
+            if (n >= 4096) hipLaunchKernelGGL((spk::k_scratch_radix2<decltype(F)::value, true>), dim3((unsigned)blocks), dim3(spk::kScratchThreads), 0, s, a);
+            else hipLaunchKernelGGL((spk::k_scratch_radix2<decltype(F)::value, false>), dim3((unsigned)blocks), dim3(spk::kScratchThreads), 0, s, a);
             return SP_OK;
         });
         if (rc) return fail(ctx, rc, "bad format");
@@ -802,16 +797,6 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     ctx->acc_dirty = false;
     return SP_OK;
 }
-
-#ifdef SP_STAMPS
-extern "C" int sp_debug_read_stamps(sp_context *ctx, unsigned long long *dst, size_t count)
-{
-    if (!ctx || !ctx->scratch.p) return SP_ERR_INVALID_ARG;
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SP_HIP(ctx, hipMemcpy(dst, ctx->scratch.p, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return SP_OK;
-}
-#endif
 
 extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *out)
 {

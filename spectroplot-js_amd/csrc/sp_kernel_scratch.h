@@ -1,7 +1,9 @@
 // sp_kernel_scratch.h — the portable frame-loop kernel: one workgroup per frame, the frame kept in an HBM/L2
-// scratch slab, one radix-2 stage per barrier.  It handles every (format, n, width, stride, layout) the library
-// accepts, including out-of-range frames and n beyond what fits in LDS.  It is the fallback behind the LDS kernel
-// (sp_kernel_lds.h) and the in-library cross-check for it; it is not the fast path.
+// scratch slab, one radix-2 stage per barrier, or four from n = 4096 (a thread takes the 16 positions that differ in the
+// four stage bits through all four stages in registers: a quarter of the slab traffic).  It handles
+// every (format, n, width, stride, layout) the library accepts, including out-of-range frames and n beyond what fits in
+// LDS.  It is the fallback behind the frame loop (sp_kernel_frames.h) and the in-library cross-check for it - written
+// with run-time loops and none of that kernel's templates - not the fast path.
 #pragma once
 
 #include "sp_kernels_common.h"
@@ -12,7 +14,53 @@ constexpr int kScratchThreads = 256;
 
 __device__ inline uint32_t bit_reverse(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
-template <int FMT>
+// Stages s0 .. s0+G-1 of the radix-2 decimation in time (fft_nayuki.js:72-88) on the slab: an item is the 2^G positions that differ
+// in bits [s0-1, s0-1+G); every butterfly of those stages inside the item pairs two of them, in the reference's operation order.
+template <int G>
+__device__ inline void scratch_stages(double *re, double *im, const double *__restrict__ cos_t, const double *__restrict__ sin_t, int n,
+                                      int levels, int s0, int tid)
+{
+    constexpr int P = 1 << G;
+    const int lowmask = (1 << (s0 - 1)) - 1;
+    for (int b = tid; b < (n >> G); b += kScratchThreads) {
+        const int low0 = b & lowmask;
+        const int base = ((b >> (s0 - 1)) << (s0 - 1 + G)) | low0;
+        double r[P], q[P];
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            r[e] = re[base | (e << (s0 - 1))];
+            q[e] = im[base | (e << (s0 - 1))];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int s = s0 + g;                                   // this stage: size 2^s, partner distance 2^(s-1) = item bit g
+#pragma unroll
+            for (int e0 = 0; e0 < P; e0++) {
+                if (e0 & (1 << g)) continue;
+                const int e1 = e0 | (1 << g);
+                // k = (position bits below bit s-1) * (n / size)                                   fft_nayuki.js:76-78
+                const int k = (low0 | ((e0 & ((1 << g) - 1)) << (s0 - 1))) << (levels - s);
+                const double c = cos_t[k], sn = sin_t[k];
+                const double tpre = r[e1] * c + q[e1] * sn;
+                const double tpim = -r[e1] * sn + q[e1] * c;
+                r[e1] = r[e0] - tpre;
+                q[e1] = q[e0] - tpim;
+                r[e0] = r[e0] + tpre;
+                q[e0] = q[e0] + tpim;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+            re[base | (e << (s0 - 1))] = r[e];
+            im[base | (e << (s0 - 1))] = q[e];
+        }
+    }
+}
+
+// WIDE: four stages per barrier (n >= 4096, where every thread still has an item); the narrow instance keeps the plain one-stage
+// loop and its small register footprint (the latency-bound small sizes need the occupancy: n = 32 ran 1.8 x slower in one kernel
+// with the 16-point items).
+template <int FMT, bool WIDE>
 __global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameArgs a)
 {
     __shared__ unsigned int s_c_hist[SP_MAX_LUT];
@@ -49,25 +97,36 @@ __global__ __launch_bounds__(kScratchThreads) void k_scratch_radix2(const FrameA
         }
         __syncthreads();
 
-        // radix-2 decimation in time, same butterfly arithmetic as fft_nayuki.js:72-88
-        for (int s = 1; s <= a.levels; s++) {
-            const int half = 1 << (s - 1);
-            for (int b = tid; b < (n >> 1); b += kScratchThreads) {
-                const int lowbits = b & (half - 1);
-                const int j = ((b >> (s - 1)) << s) | lowbits;
-                const int l = j + half;
-                const int k = lowbits << (a.levels - s);
-                const double c = a.cos_t[k], sn = a.sin_t[k];
-                const double rl = re[l], il = im[l];
-                const double tpre = rl * c + il * sn;
-                const double tpim = -rl * sn + il * c;
-                const double rj = re[j], ij = im[j];
-                re[l] = rj - tpre;
-                im[l] = ij - tpim;
-                re[j] = rj + tpre;
-                im[j] = ij + tpim;
+        // radix-2 decimation in time, same butterfly arithmetic as fft_nayuki.js:72-88, up to four stages between barriers
+        if constexpr (!WIDE) {
+            for (int s = 1; s <= a.levels; s++) {
+                const int half = 1 << (s - 1);
+                for (int b = tid; b < (n >> 1); b += kScratchThreads) {
+                    const int lowbits = b & (half - 1);
+                    const int j = ((b >> (s - 1)) << s) | lowbits;
+                    const int l = j + half;
+                    const int k = lowbits << (a.levels - s);
+                    const double c = a.cos_t[k], sn = a.sin_t[k];
+                    const double rl = re[l], il = im[l];
+                    const double tpre = rl * c + il * sn;
+                    const double tpim = -rl * sn + il * c;
+                    const double rj = re[j], ij = im[j];
+                    re[l] = rj - tpre;
+                    im[l] = ij - tpim;
+                    re[j] = rj + tpre;
+                    im[j] = ij + tpim;
+                }
+                __syncthreads();
             }
-            __syncthreads();
+        } else {
+            for (int s = 1; s <= a.levels; s += 4) {
+                const int left = a.levels - s + 1;
+                if (left >= 4) scratch_stages<4>(re, im, a.cos_t, a.sin_t, n, a.levels, s, tid);
+                else if (left == 3) scratch_stages<3>(re, im, a.cos_t, a.sin_t, n, a.levels, s, tid);
+                else if (left == 2) scratch_stages<2>(re, im, a.cos_t, a.sin_t, n, a.levels, s, tid);
+                else scratch_stages<1>(re, im, a.cos_t, a.sin_t, n, a.levels, s, tid);
+                __syncthreads();
+            }
         }
 
         if (a.channel_mode) {   // fft_nayuki.js:103-119
