@@ -47,6 +47,29 @@ struct DeviceBuffer {
     }
 };
 
+// page-locked host memory owned by a context (the landing place of a reply's small outputs)
+struct HostBuffer {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return SP_ERR_NOMEM;
+        cap = want;
+        return SP_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 }  // namespace
 
 struct sp_context {
@@ -61,6 +84,7 @@ struct sp_context {
     DeviceBuffer scratch;        // scratch kernel slabs
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small;
+    HostBuffer host_small;
     // sp_render's copy streams and events: the image goes back to the host chunk by chunk while later chunks still arrive
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     static constexpr int kMaxChunks = 8;
@@ -304,6 +328,7 @@ extern "C" void sp_context_destroy(sp_context *ctx)
     ctx->in_bytes.release();
     ctx->out_rgba.release();
     ctx->render_small.release();
+    ctx->host_small.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (int k = 0; k < sp_context::kMaxChunks; k++) {
@@ -928,8 +953,10 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     // small outputs: [c_hist L u64][cb_hist 1000 u64][minmax 2 f64][gauges 3*W u8]
     const size_t small_u64 = L + SP_CB_HIST_SIZE + 2;
     DeviceBuffer &small = ctx->render_small;
-    if (!rc) rc = small.reserve(small_u64 * 8 + 3 * W + 16);
-    if (rc) return fail(ctx, rc, "sp_render: out of device memory");
+    const size_t small_bytes = small_u64 * 8 + 3 * W;
+    if (!rc) rc = small.reserve(small_bytes + 16);
+    if (!rc) rc = ctx->host_small.reserve(small_bytes + 16);
+    if (rc) return fail(ctx, rc, "sp_render: out of memory");
     uint64_t *d_c = (uint64_t *)small.p, *d_cb = d_c + L;
     double *d_mm = (double *)(d_cb + SP_CB_HIST_SIZE);
     uint8_t *d_g = (uint8_t *)(d_mm + 2);
@@ -963,8 +990,7 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
         }
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render streams");
     }
-    e = hipMemsetAsync(small.p, 0, small_u64 * 8, s);
-    if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
+    // (nothing to clear: the finish kernel overwrites every histogram count, both range values and every gauge byte)
     if (chunks == 1) {
         if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
@@ -1021,18 +1047,23 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
         if (dst && bytes_ && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, s);
     };
     if (chunks == 1) down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
-    down(reply->gauge_mins, d.gauge_mins, W);
-    down(reply->gauge_maxs, d.gauge_maxs, W);
-    down(reply->gauge_amps, d.gauge_amps, W);
-    down(reply->c_hist, d_c, L * 8);
-    down(reply->cb_hist, d_cb, SP_CB_HIST_SIZE * 8);
-    down(reply->dbfs_minmax, d_mm, 16);
+    // the six small outputs sit side by side on the device: one copy into the context's page-locked block, handed out from there
+    // (six separate copies into pageable memory cost more than the kernels of a small request)
+    down(ctx->host_small.p, small.p, small_bytes);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (chunks > 1) {
         const hipError_t e2 = hipStreamSynchronize(ctx->copy_out);
         if (e == hipSuccess) e = e2;
     }
     if (e != hipSuccess) return hip_fail(ctx, e, "sp_render download");
+    const uint8_t *h = (const uint8_t *)ctx->host_small.p;
+    const uint8_t *h_g = h + small_u64 * 8;
+    if (reply->c_hist) memcpy(reply->c_hist, h, L * 8);
+    if (reply->cb_hist) memcpy(reply->cb_hist, h + L * 8, SP_CB_HIST_SIZE * 8);
+    if (reply->dbfs_minmax) memcpy(reply->dbfs_minmax, h + (L + SP_CB_HIST_SIZE) * 8, 16);
+    if (reply->gauge_mins) memcpy(reply->gauge_mins, h_g, W);
+    if (reply->gauge_maxs) memcpy(reply->gauge_maxs, h_g + W, W);
+    if (reply->gauge_amps) memcpy(reply->gauge_amps, h_g + 2 * W, W);
     return SP_OK;
 }
 

@@ -10,10 +10,12 @@ pkg = load_package()
 from spectroplot_js_amd import binding as B
 ctx = pkg.Context(0)
 L = ctx.lib.L
-n, fmt = 1024, "CF32"
-W = 16384; S = W * n
+# python3 tools/host_path.py [cfg2 | cfg1]   (cfg1: 1 MSample cu8, n = 512: the small-message case)
+CFG = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+n, fmt, W = (512, "CU8", 2048) if CFG == "cfg1" else (1024, "CF32", 16384)
+S = W * n
 data = siggen.generate(fmt, {"kind": "trinoise", "seed": 0x5EED0001, "step": 7321, "gshift": 11, "amp": 0.5, "namp": 0.02}, S)
-win, weight = pkg.window("blackmanHarris", n)
+win, weight = pkg.window("hann" if CFG == "cfg1" else "blackmanHarris", n)
 i = np.arange(256)
 lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
 fid, _ = B.parse_format(fmt)
@@ -27,7 +29,7 @@ def pinned(nbytes):
     return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
 
 
-def run(inp, out_rgba, fresh_out, reps=10):
+def run(inp, out_rgba, fresh_out, reps=10 if CFG == "cfg2" else 200):
     small = [np.zeros(W, np.uint8) for _ in range(3)] + [np.zeros(256, np.uint64), np.zeros(1000, np.uint64), np.zeros(2)]
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     ts = []
@@ -48,4 +50,4 @@ for name, inp, out, fresh in (("pageable request, fresh pageable reply", data, N
                               ("pageable request, page-locked reply", data, pin_out, False), ("page-locked request and reply", pin_in, pin_out, False)):
     ms, total = run(inp, out, fresh)
     assert total == W * n
-    print("sp_render cfg2, %-42s %6.2f ms per request = %5.1f GB/s over PCIe both ways" % (name + ":", ms, (data.nbytes + 4 * W * n) / ms / 1e6))
+    print("sp_render " + CFG + ", %-42s %6.3f ms per request = %5.1f GB/s over PCIe both ways" % (name + ":", ms, (data.nbytes + 4 * W * n) / ms / 1e6))
