@@ -55,3 +55,35 @@ def test_no_kernel_of_the_product_touches_a_register_with_an_outstanding_lds_rea
         bad += c.check_listing(lines, os.path.basename(o))
     assert reads > 5000            # the asm reads are there (16 per component and re-distribution in every variant)
     assert not bad, bad[:10]
+
+
+def test_the_prefetching_iq_variants_of_the_frame_loop_use_no_scratch_memory():
+    """A kernel that touches scratch (spilled VGPRs, or the argument structure dropped to the stack because a lambda was not inlined: it
+    happened in an experiment and cost 40 %) launches its waves slower and reads its arguments from memory.  Every variant the BASELINE
+    configs run - interleaved I/Q, samples prefetched (PFB != 0) - must have a private segment of zero bytes and no spilled VGPR."""
+    import re
+    import subprocess
+    import tempfile
+    objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "frames_*.o")))
+    if len(objs) < 8:
+        build()
+        objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "frames_*.o")))
+    assert len(objs) == 8
+    llvm = "/opt/rocm/lib/llvm/bin"
+    seen = 0
+    with tempfile.TemporaryDirectory() as t:
+        for o in objs:
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, os.path.join(t, "fb.bin")])
+            subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + os.path.join(t, "fb.bin"),
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + os.path.join(t, "k.co")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(t, "k.co")], text=True)
+            for blk in notes.split(".name:")[1:]:
+                m = re.match(r"\s*_ZN4spk28k_framesILi(\d+)ELb([01])ELi(\d+)E", blk)
+                if not m or m.group(2) == "1" or m.group(3) == "0":
+                    continue
+                seen += 1
+                priv = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1))
+                spill = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", blk).group(1))
+                assert priv == 0 and spill == 0, (m.group(0), priv, spill)
+    assert seen == 8 * 5           # eight sizes x five prefetch widths
