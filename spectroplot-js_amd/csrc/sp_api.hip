@@ -79,8 +79,8 @@ struct sp_context {
     std::string error;
     int cu_count = 256;
     // workspace of the frame loop
-    DeviceBuffer frame_minmax;   // 2 * width doubles
-    DeviceBuffer partial;        // finish-kernel state: ticket, {min,max} accumulator, histogram accumulators
+    DeviceBuffer frame_minmax;   // 2 * width doubles (the scratch kernel's frame extremes, read by k_finish_frames)
+    DeviceBuffer partial;        // [0,4) the number of the last request k_frames has started; the scratch kernel's {min,max} and histogram accumulators
     DeviceBuffer scratch;        // scratch kernel slabs
     // staging for sp_render (host-buffer entry point)
     DeviceBuffer in_bytes, out_rgba, render_small;
@@ -98,8 +98,8 @@ struct sp_context {
     std::vector<uint8_t> named_lut;
     double named_block_norm = 0;
     long long plans_created = 0; // sp_context_plan_creations: how many plans (table sets on the device) this context has built
-    bool acc_dirty = false;      // a request failed between its two kernels: accumulators must be re-initialised
-    int cell_toggle = 0;         // which of the two merged-cell buffers the next k_frames launch counts into
+    bool acc_dirty = false;      // a request failed between its launches: accumulators must be re-initialised
+    uint32_t seq = 0;            // requests started on this context (k_frames publishes the number once the reply is cleared; never 0)
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -627,8 +627,9 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 }
 
 // The frame loop over frames [x_begin, x_end) of a width-frame image.  `first` prepares the context's workspace and accumulators,
-// `last` queues the finish kernel (gauges, histograms, dBfs range of the whole request).  sp_plan_execute is the whole range in one
-// launch; sp_render walks the image in chunks so that the copies to and from the host overlap.
+// `last` ends the request: k_frames then produces histograms and dBfs range itself (its last workgroup; the gauges it writes group by
+// group in every launch), behind the scratch kernel a finish kernel is queued.  sp_plan_execute is the whole range in one launch - ONE
+// kernel for every request k_frames covers; sp_render walks the image in chunks so that the copies to and from the host overlap.
 static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, int32_t x_begin, int32_t x_end, bool first,
                               bool last, const sp_reply *out)
 {
@@ -671,28 +672,19 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         }
     }
 
-    int rc = ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
-    if (rc) return fail(ctx, rc, "workspace: out of device memory");
     const int which = plan_kernel(plan);
+    int rc = which == 3 ? SP_OK : ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
+    if (rc) return fail(ctx, rc, "workspace: out of device memory");
     int finish_blocks = 3 * ((width + spk::kFinishThreads - 1) / spk::kFinishThreads);   // three roles per 256 frames
-    int finish_gauge_block0 = 0;
     {
         const int bins = plan->req.lut_len > SP_CB_HIST_SIZE ? plan->req.lut_len : SP_CB_HIST_SIZE;   // it also moves the histograms
         const int hb = (bins + spk::kFinishThreads - 1) / spk::kFinishThreads;
-        if (which == 3) {            // merged cells: the histogram workgroups serve no frames
-            finish_gauge_block0 = hb;
-            finish_blocks += hb;
-        }
         if (finish_blocks < hb) finish_blocks = hb;
-        const int cb = (spk2::kMaxCells * spk2::kCellCopies + spk::kFinishThreads - 1) / spk::kFinishThreads;
-        if (finish_blocks < cb) finish_blocks = cb;
         finish_blocks += 1;          // the dBfs range: a workgroup of its own, behind neither the histograms nor a gauge
     }
-    // [16,32) bit patterns of the extreme |X|^2 of a launch, [64, ...) colour and centi-bel histogram accumulators
-    // ... and two merged-cell buffers for k_frames (one counts while the finish kernel of the previous launch reads the other)
-    const size_t cell_off = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
-    const size_t cell_buf_words = (size_t)spk2::kMaxCells * spk2::kCellCopies;
-    const size_t acc_bytes = cell_off + 2 * cell_buf_words * sizeof(unsigned long long);
+    // [0,4) k_frames: the number of the last request whose reply workgroup 0 has cleared; scratch kernel: [16,32) bit patterns of the
+    // extreme |X|^2 of a request, [64, ...) colour and centi-bel histogram accumulators, back at their initial values when a request ends
+    const size_t acc_bytes = 64 + (SP_MAX_LUT + SP_CB_HIST_SIZE) * sizeof(unsigned long long);
     const bool fresh_partial = ctx->partial.cap < acc_bytes;
     rc = ctx->partial.reserve(acc_bytes);
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
@@ -743,15 +735,27 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     a.frame_min = (double *)ctx->frame_minmax.p;
     a.frame_max = a.frame_min + width;
     a.scratch = nullptr;
+    if (first && ++ctx->seq == 0) ctx->seq = 1;
+    a.first = first ? 1 : 0;
+    a.seq = ctx->seq;
+    a.flag = (unsigned int *)ctx->partial.p;
+    a.gauge_mins = out->gauge_mins;
+    a.gauge_maxs = out->gauge_maxs;
+    a.gauge_amps = out->gauge_amps;
+    a.block_norm_db = plan->block_norm_db;
+    a.gain = plan->req.gain;
+    a.range = plan->req.range;
+    a.out_c = (unsigned long long *)out->c_hist;
+    a.out_cb = (unsigned long long *)out->cb_hist;
+    a.out_minmax = out->dbfs_minmax;
+    a.cell_g = plan->d_cell_g;
+    a.cell_l = plan->d_cell_l;
 
     // the kernels count into the context's accumulators; the finish kernel moves the counts to the reply
     a.mm_acc = (unsigned long long *)((char *)ctx->partial.p + 16);
     a.c_hist = (unsigned long long *)((char *)ctx->partial.p + 64);
     a.cb_hist = a.c_hist + SP_MAX_LUT;
-    unsigned long long *const cell_buf = (unsigned long long *)((char *)ctx->partial.p + cell_off);
-    a.cell_acc = cell_buf + (size_t)ctx->cell_toggle * cell_buf_words;
     a.cells = plan->th.cells;
-    a.cells_cap = spk2::kMaxCells;
     a.rgba_fast = out->rgba && ((uintptr_t)out->rgba & 15) == 0 && (width & 3) == 0 && width < (1 << 24)
                   && (double)width * (double)n * 4.0 <= 4294967296.0;
 
@@ -782,6 +786,10 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     }
 
     if (!last) return SP_OK;
+    if (which == 3) {   // k_frames has finished the request itself
+        ctx->acc_dirty = false;
+        return SP_OK;
+    }
 
     spk::FinishArgs fa{};
     fa.bytes = a.bytes;
@@ -806,17 +814,6 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     fa.acc_cb = a.cb_hist;
     fa.out_c = (unsigned long long *)out->c_hist;
     fa.out_cb = (unsigned long long *)out->cb_hist;
-    if (which == 3) {
-        fa.cell_acc = a.cell_acc;
-        fa.cell_clear = cell_buf + (size_t)(ctx->cell_toggle ^ 1) * cell_buf_words;
-        fa.cell_g = plan->d_cell_g;
-        fa.cell_l = plan->d_cell_l;
-        fa.cells = plan->th.cells;
-        fa.cells_cap = spk2::kMaxCells;
-        fa.cell_copies = spk2::kCellCopies;
-        fa.gauge_block0 = finish_gauge_block0;
-        ctx->cell_toggle ^= 1;
-    }
     hipLaunchKernelGGL(spk::k_finish_frames, dim3((unsigned)finish_blocks), dim3(spk::kFinishThreads), 0, s, fa);
     SP_HIP(ctx, hipGetLastError());
     ctx->acc_dirty = false;

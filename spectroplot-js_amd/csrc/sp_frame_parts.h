@@ -18,7 +18,8 @@
 //   * Twiddles: per-stage tables (PassTw, load_pass_tw), in LDS for the early stages and in L2 above; the reads of a pass go
 //     out as one batch ahead of its re-distribution.
 //   * Input: thread tl of a frame owns positions 16*tl + e, i.e. samples rev4(e)*T + rev(tl): every load instruction
-//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.  1-, 2-, 3-, 4-
+//     of a frame covers one contiguous run of T samples (whole cache lines), permuted across lanes.  (Register 1 of thread 0 is
+//     sample n/2, the frame's raw centre sample: the loaders hand it out for gauge_amps, worker.js:130-131.)  1-, 2-, 3-, 4-
 //     and 8-byte samples are requested one frame ahead into registers (issue_raw, decode_frame); the other formats and frames
 //     that leave the buffer take the checked loaders (load_frame).
 #pragma once
@@ -236,7 +237,7 @@ __device__ inline void exchange_permlane(double (&v)[16])
 
 template <int FMT>
 __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, int64_t start, int tl, int T, int levels,
-                                  const double (&win)[16], double (&re)[16], double (&im)[16])
+                                  const double (&win)[16], double (&re)[16], double (&im)[16], double2 *centre)
 {
     const int sidx = (int)(__brev((unsigned)tl) >> (32 - (levels - 4)));   // rev_{L-4}(tl)
     if (a.in_bounds) {
@@ -249,6 +250,7 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
             re[e] = win[e] * vi[e];                                            // worker.js:73-74
             im[e] = win[e] * vq[e];
         }
+        if (centre) *centre = make_double2(vi[1], vq[1]);
     } else {
 #pragma unroll 1
         for (int e = 0; e < 16; e++) {
@@ -256,6 +258,7 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
             // runtime register index: keep this rare path small (it is only taken when frames leave the buffer)
             const double vi = spfmt::sample_checked<FMT>(view, pos, 0);
             const double vq = spfmt::sample_checked<FMT>(view, pos, 1);
+            if (e == 1 && centre) *centre = make_double2(vi, vq);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k == e) {
@@ -300,7 +303,7 @@ __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start
 // Returns true if the frame may hold infinities or NaNs (float formats; integer formats never do).
 template <int FMT, int NHI>
 __device__ inline bool decode_frame(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI], const double (&win)[16], double (&re)[16],
-                                    double (&im)[16], int shift = 0)
+                                    double (&im)[16], double2 *centre, int shift = 0)
 {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -308,6 +311,8 @@ __device__ inline bool decode_frame(const uint32_t (&lo)[16], const uint32_t (&h
         spfmt::decode_raw<FMT>((FMT == SP_FMT_CU12 || FMT == SP_FMT_CS12) ? lo[e] >> shift : lo[e], hi[NHI == 16 ? e : 0], vi, vq);
         re[e] = win[e] * vi;                                                   // worker.js:73-74
         im[e] = win[e] * vq;
+        // thread 0 of the frame: sample n/2, the raw centre sample of gauge_amps (worker.js:130-131), straight to its LDS slot
+        if (e == 1 && centre) *centre = make_double2(vi, vq);
     }
     // A float capture may hold them, and telling costs as much as the products it would save (32 v_cmp_class per lane-frame
     // plus a second copy of the first pass: measured 28 % slower), so float frames keep the full butterflies.

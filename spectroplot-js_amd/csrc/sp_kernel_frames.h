@@ -67,7 +67,6 @@ inline constexpr Tw16 kTw16Host[8] = {
 
 constexpr int kMmSlotsMax = 4;
 constexpr int kMaxCells = kLdsMaxLut + SP_CB_HIST_SIZE + 2;   // merged histogram cells (sp_host.h Thresholds)
-constexpr int kCellCopies = 8;                               // accumulator copies, one per XCD
 
 __host__ __device__ inline constexpr int mm_slots(int n)
 {
@@ -100,7 +99,7 @@ __host__ __device__ inline int group_frames_for(int n, int want)
 }
 
 struct Layout {
-    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_win, total;
+    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_amp, off_win, total;
 };
 
 __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames)
@@ -116,8 +115,9 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames)
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
-    l.off_done = o;   o += 32;                                   // arrival counters: the two wave sets (last write-out), the frames' waves
-    o = (o + 7) & ~7;
+    l.off_done = o;   o += 32;                                   // arrival counters: the two wave sets (last write-out), the frames' waves; [7]: "last workgroup"
+    o = (o + 15) & ~15;
+    l.off_amp = o;    o += 16 + 2 * group_frames * 16;           // the workgroup's extreme |X|^2 so far; raw centre samples of two groups' frames
     l.off_win = o;    o += lds_win_in_lds(n) ? n * 8 : 0;
     l.total = (o + 15) & ~15;
     return l;
@@ -139,12 +139,35 @@ __device__ inline double max_raw(double a, double b)
     return r;
 }
 
+// Fire-and-forget LDS minimum / maximum of doubles (no NaN operands here).  As instructions: the compiler's atomic optimiser turns
+// an atomic with a wave-uniform address into a loop over the active lanes, ~10 instructions per lane; the LDS serialises the lanes itself.
+__device__ inline void lds_min_f64(double *p, double v)
+{
+    asm volatile("ds_min_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)p), "v"(v) : "memory");
+}
+__device__ inline void lds_max_f64(double *p, double v)
+{
+    asm volatile("ds_max_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)p), "v"(v) : "memory");
+}
+
 // 16-byte non-temporal store (dst is 16-byte aligned)
 __device__ inline void store_nt(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = {a, b, c, d};
     __builtin_nontemporal_store(v, (u32x4 *)dst);
+}
+
+// The launch arguments as they lie in the kernel-argument segment (FrameArgs is k_frames' first parameter), behind an opaque copy of
+// the segment pointer: fields read through it are fetched (s_load) where they are used - the side outputs once per group, the
+// request's end - instead of sitting in SGPRs from the kernel's first instruction on (the compiler loads every field of a by-value
+// argument it can see at the entry; the two dozen that only the side outputs need cost as many spilled SGPRs in the frame loop).
+typedef const __attribute__((address_space(4))) FrameArgs *LateArgs;
+__device__ inline LateArgs late_args()
+{
+    LateArgs p = (LateArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
 
 // First register pass: stages 1-4 inside window [0, 4) with literal twiddles.
@@ -280,6 +303,8 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
     unsigned int *s_cells = (unsigned int *)(smem + lay.off_cells);      // word c counts the pixels with colour index + level == c
     [[maybe_unused]] unsigned int *s_done = (unsigned int *)(smem + lay.off_done);
+    double *s_red = (double *)(smem + lay.off_amp);                           // the workgroup's share of dBfs_min / dBfs_max so far
+    double2 *s_amp = (double2 *)(smem + lay.off_amp + 16);                    // [2][group_frames] (I, Q) of sample n/2, by group parity
 
     const int tid = threadIdx.x;
     [[maybe_unused]] const int lane = tid & 63;
@@ -316,6 +341,8 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     const int fs0 = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + fs % (FPB / 2) : fs;     // the slot's frame in a group's first round
     if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
 
+    // workgroup 0's first wave owns the reply's initial state in the first launch of a request (below)
+    const bool owner = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(tid >> 6) == 0 && a.first;   // (wave-uniform)
     constexpr bool WIN_LDS = lds_win_in_lds(N);   // taper in LDS for n <= 1024, in registers for the whole launch above
     double *s_win = (double *)(smem + lay.off_win);
     constexpr int MMS = mm_slots(N);
@@ -346,9 +373,27 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             const int i = tid + k * kThreads;
             cb_r[k] = i <= SP_CB_HIST_SIZE ? a.cb_edge[i] : 0.0;
         }
+        // Workgroup 0 of a request's first launch clears the reply's histograms and sets its dBfs range to (0, -200): its first wave
+        // alone, so that the wave knows when the stores have landed (publish() below).  Fire-and-forget, behind the table loads.
+        if (owner) {
+            const LateArgs la = late_args();
+            unsigned long long *const out_c = la->out_c, *const out_cb = la->out_cb;
+            unsigned long long *const out_mm = (unsigned long long *)la->out_minmax;
+            constexpr int kClr = (kLdsMaxLut + SP_CB_HIST_SIZE + 63) / 64;
+#pragma unroll
+            for (int k = 0; k < kClr; k++) {
+                const int i = tid + 64 * k;
+                unsigned long long *const dst = i < kLdsMaxLut ? (out_c && i < a.lut_len ? out_c + i : nullptr)
+                                                               : (out_cb && i < kLdsMaxLut + SP_CB_HIST_SIZE ? out_cb + (i - kLdsMaxLut) : nullptr);
+                if (dst) __hip_atomic_store(dst, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 2 && out_mm)
+                __hip_atomic_store(out_mm + tid, tid ? 0xc069000000000000ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // -200.0, 0.0
+        }
         // what needs no table is set up while the loads are in flight (a table load takes ~2.3 us at the start of a launch)
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
         if (tid < 8) s_done[tid] = 0;
+        if (tid < 2) s_red[tid] = tid ? -200.0 : 0.0;                             // worker.js:35-36
         for (int i = tid; i < group_frames * MMS; i += kThreads) {
             s_mm[2 * i] = 0x7ff0000000000000ull;
             s_mm[2 * i + 1] = 0ull;
@@ -393,30 +438,53 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     const float g_lo = 0.5f, g_hi = (float)cmax + 0.5f;
     const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
 
-    unsigned long long blk_mn = 0x7ff0000000000000ull, blk_mx = 0ull;   // threads < group_frames: over their frames
-    // write-out of tile rows [f0, f0 + fcount) by the threads [t0, t0 + dthreads), slice `part` of `nparts`; slice 0 of a whole-group
-    // call also hands over the frames' extremes
-    auto drain_rows = [&](const int x0, const int part, const int nparts, const int f0, const int fcount, const int t0, const int dthreads,
-                          const bool extremes, const bool nt_rows) {
-        const int dt = tid - t0;
-        if (extremes && part == 0 && tid < group_frames) {
-            if (x0 + tid < a.x_end) {
-                unsigned long long bmn = 0x7ff0000000000000ull, bmx = 0ull;
+    // Side outputs of a finished group of frames (worker.js:124-136), by the workgroup's first 3 * group_frames threads: gauge_mins and
+    // gauge_maxs from the frame's extreme |X|^2 (d is monotone in |X|^2, so the frame's extreme d belong to them), gauge_amps from its
+    // raw centre sample: one software log10 per output.  The frame's clamped extremes are also its share of the request's dBfs range
+    // (worker.js:124-125): they are folded into the workgroup's; the frame's slots are reset.
+    auto side_outputs = [&](const int x0, const int par) {
+        if (__builtin_amdgcn_readfirstlane(tid) >= 3 * group_frames) return;   // (wave-uniform: the waves that hold none of those threads)
+        const LateArgs la = late_args();
+        // three scalar loads, selected per lane below (the compiler turns a select between fields into ONE indexed vector load, whose
+        // wait covers every outstanding vector-memory operation of the wave: the sample prefetch, ~2 us)
+        uint8_t *out_min = la->gauge_mins, *out_max = la->gauge_maxs, *out_amp = la->gauge_amps;
+        asm volatile("" : "+s"(out_min), "+s"(out_max), "+s"(out_amp));
+        const double gain = la->gain, range = la->range, bn_db = la->block_norm_db;
+        if (tid >= 3 * group_frames) return;
+        const int role = (tid >= group_frames ? 1 : 0) + (tid >= 2 * group_frames ? 1 : 0), f = tid - role * group_frames;
+        double arg;
+        if (role < 2) {
+            unsigned long long ext = role ? 0ull : 0x7ff0000000000000ull;
 #pragma unroll
-                for (int k = 0; k < MMS; k++) {
-                    const ulonglong2 v = *(const ulonglong2 *)(s_mm + 2 * (tid * MMS + k));
-                    bmn = v.x < bmn ? v.x : bmn;
-                    bmx = v.y > bmx ? v.y : bmx;
-                }
-                a.frame_min[x0 + tid] = __longlong_as_double((long long)bmn);
-                a.frame_max[x0 + tid] = __longlong_as_double((long long)bmx);
-                blk_mn = bmn < blk_mn ? bmn : blk_mn;
-                blk_mx = bmx > blk_mx ? bmx : blk_mx;
+            for (int k = 0; k < MMS; k++) {
+                unsigned long long *slot = s_mm + 2 * (f * MMS + k) + role;
+                const unsigned long long v = *slot;
+                ext = role ? (v > ext ? v : ext) : (v < ext ? v : ext);
+                *slot = role ? 0ull : 0x7ff0000000000000ull;
             }
-#pragma unroll
-            for (int k = 0; k < MMS; k++)
-                *(ulonglong2 *)(s_mm + 2 * (tid * MMS + k)) = make_ulonglong2(0x7ff0000000000000ull, 0ull);
+            arg = __longlong_as_double((long long)ext);
+        } else {
+            const double2 c = s_amp[par * group_frames + f];
+            arg = c.x * c.x + c.y * c.y;                                                       // worker.js:130-131
         }
+        const double l5 = 5 * spjs::log10(arg);
+        double v;
+        if (role == 2) {
+            v = l5 + gain;
+        } else {
+            const double d = (l5 + bn_db + gain) - gain;                                       // dBfs - gain, worker.js:100
+            v = role ? (d > -200.0 ? d : -200.0) : (d < 0.0 ? d : 0.0);                        // worker.js:82-83, 102-103
+            if (role) lds_max_f64(&s_red[1], v);
+            else lds_min_f64(&s_red[0], v);
+        }
+        uint8_t *const out = role == 0 ? out_min : role == 1 ? out_max : out_amp;
+        if (out && x0 + f < a.x_end) out[x0 + f] = clamp_u8(0.5 + (range + v) * 256 / range);   // worker.js:128-136
+    };
+    // write-out of tile rows [f0, f0 + fcount) by the threads [t0, t0 + dthreads), slice `part` of `nparts`
+    auto drain_rows = [&](const int x0, const int part, const int nparts, const int f0, const int fcount, const int t0, const int dthreads,
+                          const bool nt_rows) {
+        const int dt = tid - t0;
+        if (dt < 0) return;
         if (a.rgba) {
             if (!a.waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
@@ -508,8 +576,9 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         }
     };
     // non-temporal stores where a group's row pieces are whole 128-byte lines (below)
-    auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, true, group_frames >= 32); };
+    auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, group_frames >= 32); };
     int drain_x0 = -1;
+    int gpar = 0;   // parity of the workgroup's current group (s_amp)
     meet.arrive();   // the first re-distribution only waits (exchange<.., SECOND = false>)
     for (int g = xcd * chunk + lane_in_xcd; g < g_end; g += per_xcd) {
         const int x0 = a.frame0 + g * group_frames;
@@ -525,6 +594,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
 
             double re[16], im[16];
             double win[16];
+            double2 *const centre = tl == 0 ? &s_amp[gpar * group_frames + fr] : nullptr;   // thread 0 of the frame: where its raw centre sample goes
             bool nonfinite = true;   // wave-uniform
 #pragma unroll
             for (int e = 0; e < 16; e++) win[e] = WIN_LDS ? wbase[e * T] : win_reg[WIN_LDS ? 0 : e];
@@ -534,22 +604,22 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             if constexpr (PF && LATE_PF) request(xr);
             if constexpr (PF) {
                 if constexpr (PFB == 1) {
-                    if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im);
-                    else nonfinite = decode_frame<SP_FMT_CS4, 1>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU4) nonfinite = decode_frame<SP_FMT_CU4, 1>(raw_lo, raw_hi, win, re, im, centre);
+                    else nonfinite = decode_frame<SP_FMT_CS4, 1>(raw_lo, raw_hi, win, re, im, centre);
                 } else if constexpr (PFB == 3) {
-                    if (format == SP_FMT_CU12) nonfinite = decode_frame<SP_FMT_CU12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
-                    else nonfinite = decode_frame<SP_FMT_CS12, 1>(raw_lo, raw_hi, win, re, im, 8 * raw_back);
+                    if (format == SP_FMT_CU12) nonfinite = decode_frame<SP_FMT_CU12, 1>(raw_lo, raw_hi, win, re, im, centre, 8 * raw_back);
+                    else nonfinite = decode_frame<SP_FMT_CS12, 1>(raw_lo, raw_hi, win, re, im, centre, 8 * raw_back);
                 } else if constexpr (PFB == 2) {
-                    if (format == SP_FMT_CU8) nonfinite = decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im);
-                    else nonfinite = decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU8) nonfinite = decode_frame<SP_FMT_CU8, 1>(raw_lo, raw_hi, win, re, im, centre);
+                    else nonfinite = decode_frame<SP_FMT_CS8, 1>(raw_lo, raw_hi, win, re, im, centre);
                 } else if constexpr (PFB == 4) {
-                    if (format == SP_FMT_CU16) nonfinite = decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im);
-                    else nonfinite = decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU16) nonfinite = decode_frame<SP_FMT_CU16, 1>(raw_lo, raw_hi, win, re, im, centre);
+                    else nonfinite = decode_frame<SP_FMT_CS16, 1>(raw_lo, raw_hi, win, re, im, centre);
                 } else {
-                    if (format == SP_FMT_CU32) nonfinite = decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im);
-                    else if (format == SP_FMT_CS32) nonfinite = decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im);
+                    if (format == SP_FMT_CU32) nonfinite = decode_frame<SP_FMT_CU32, 16>(raw_lo, raw_hi, win, re, im, centre);
+                    else if (format == SP_FMT_CS32) nonfinite = decode_frame<SP_FMT_CS32, 16>(raw_lo, raw_hi, win, re, im, centre);
                     else {
-                        decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im);
+                        decode_frame<SP_FMT_CF32, 16>(raw_lo, raw_hi, win, re, im, centre);
                         nonfinite = raw_f32_nonfinite<16>(raw_lo, raw_hi);
                     }
                 }
@@ -562,12 +632,12 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     for (int l = tl; l < lines; l += T) pf_word = *(const uint32_t *)(a.bytes + ((nb + (int64_t)l * 128) & ~(int64_t)3));
                 }
                 switch (format) {
-#define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im); break;
+#define SP_CASE(F) case F: load_frame<F>(a, view, start, tl, T, LOG2N, win, re, im, centre); break;
                     SP_CASE(SP_FMT_CU4) SP_CASE(SP_FMT_CS4) SP_CASE(SP_FMT_CU8) SP_CASE(SP_FMT_CS8) SP_CASE(SP_FMT_CU12)
                     SP_CASE(SP_FMT_CS12) SP_CASE(SP_FMT_CU16) SP_CASE(SP_FMT_CS16) SP_CASE(SP_FMT_CU32) SP_CASE(SP_FMT_CS32)
                     SP_CASE(SP_FMT_CU64) SP_CASE(SP_FMT_CS64) SP_CASE(SP_FMT_CF32)
 #undef SP_CASE
-                default: load_frame<SP_FMT_CF64>(a, view, start, tl, T, LOG2N, win, re, im); break;
+                default: load_frame<SP_FMT_CF64>(a, view, start, tl, T, LOG2N, win, re, im, centre); break;
                 }
             }
 
@@ -577,6 +647,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             // the previous group's write-out goes in two slices around this frame's passes, so that its stores drain while the SIMDs compute
             if (drain_x0 >= 0) {
                 lds_barrier();
+                side_outputs(drain_x0, gpar ^ 1);
                 drain(drain_x0, 0, 2);
             }
             // ---- first pass: literal twiddles ------------------------------------------------------------------------------
@@ -805,11 +876,34 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
+            // Workgroup 0's first wave publishes the request's number once its clearing stores have landed: after its first frame (group 0
+            // is workgroup 0's, and every slot has a frame in a group's first round), when they long have.
+            if (g == 0 && r == 0 && a.first && __builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const LateArgs la = late_args();
+                if (tid == 0) __hip_atomic_store(la->flag, la->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         drain_x0 = x0;
+        gpar ^= 1;
     }
 
-    // ---- end of the workgroup's frames: histograms to the context accumulators, last write-out -------------------------
+    // ---- end of the workgroup's frames: last write-out and side outputs, the workgroup's share of histograms and dBfs range ----------
+    const LateArgs la = late_args();
+    // requested now, used behind the last barrier: the cell ranges of this thread's histogram outputs and the request's number as
+    // workgroup 0 published it
+    const uint16_t *const cell_g = la->cell_g, *const cell_l = la->cell_l;
+    const int gi_c = tid < a.lut_len ? tid : 0;
+    const int cg_lo = cell_g[gi_c], cg_hi = cell_g[gi_c + 1];
+    int l_lo[2], l_hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int gi = tid + u * kThreads;
+        const int l_cb = gi < SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE - 1 - gi : 0;              // bin gi counts level 999 - gi
+        l_lo[u] = cell_l[l_cb];
+        l_hi[u] = cell_l[l_cb + 1];
+    }
+    const unsigned int seen = __hip_atomic_load(la->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (HALVES && drain_x0 >= 0 && a.rgba) {
         // The workgroup's last write-out overlaps nothing.  The first waves of the SIMDs reach it ~7 us before the second ones (config 2;
         // issue arbitration favours the older wave, s_setprio does not change that - tools/stamps.py) and would wait at the barrier:
@@ -821,27 +915,76 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         while (__hip_atomic_load(&s_done[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u) __builtin_amdgcn_s_sleep(2);
         // (non-temporal: left in L2, the 64-byte pieces are written back when the kernel ends, +1.2 us instead of -1.1 us; the first
         // set also taking half of the second set's rows once those are ready: no further gain)
-        drain_rows(drain_x0, 0, 1, half * (group_frames / 2), group_frames / 2, half * (kThreads / 2), kThreads / 2, false, true);
+        drain_rows(drain_x0, 0, 1, half * (group_frames / 2), group_frames / 2, half * (kThreads / 2), kThreads / 2, true);
     }
     lds_barrier();
-    for (int i = tid; i < a.cells; i += kThreads) {
-        const unsigned int v = s_cells[i];
-        // one copy per XCD (workgroups b and b + 8 share one): 32 adders per word instead of 256
-        if (v) atomicAdd(&a.cell_acc[(size_t)xcd * a.cells_cap + i], (unsigned long long)v);
-    }
     if (drain_x0 >= 0) {
-        if (HALVES && a.rgba) drain_rows(drain_x0, 0, 1, 0, 0, 0, kThreads, true, false);   // the extremes only
-        else drain(drain_x0, 0, 1);
+        side_outputs(drain_x0, gpar ^ 1);
+        if (!(HALVES && a.rgba)) drain(drain_x0, 0, 1);
+    }
+    // ---- the workgroup's share of the request's histograms and dBfs range (worker.js:105-113, 124-125, 140-155) ----------------------
+    // No workgroup finishes for the others (that costs the last one three dependent trips to memory, 6 us): every workgroup turns its
+    // own merged cells into histogram counts and adds them to the reply itself, with fire-and-forget atomics the launch's end waits
+    // for anyway.  Workgroup 0 has zeroed the reply's histograms and set its dBfs range to (0, -200) at the start of the request's
+    // first launch and published the request's number behind that (below); everybody checks the number before its first add.
+    {
+        // cells -> prefix sums: every count is a difference of two prefix sums over the cells (sp_host.h Thresholds).  A thread takes
+        // kPer consecutive cells, the workgroup scans the 512 partial sums (in each wave with shuffles, the eight wave totals through
+        // LDS).  The exchange buffers are idle by now and hold the prefix.  (Counts of one workgroup fit 32 bits, as s_cells does.)
+        constexpr int kPer = 3;
+        static_assert(kThreads * kPer >= kMaxCells, "every cell needs a thread");
+        unsigned int *const s_pre = (unsigned int *)smem;                     // [kThreads * kPer + 1]: s_pre[c] = sum of the cells [0, c)
+        unsigned int *const s_part = s_pre + kThreads * kPer + 4;             // [kThreads / 64] wave totals
+        unsigned int v[kPer], run = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int c = tid * kPer + k;
+            v[k] = c < a.cells ? s_cells[c] : 0u;
+            run += v[k];
+        }
+        unsigned int incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_part[tid >> 6] = incl;
         lds_barrier();
-    }
-    if (tid < group_frames) {
-        if (blk_mn != 0x7ff0000000000000ull) atomicMin(&s_mm[0], blk_mn);
-        if (blk_mx != 0ull) atomicMax(&s_mm[1], blk_mx);
-    }
-    lds_barrier();
-    if (tid == 0) {
-        if (s_mm[0] != 0x7ff0000000000000ull) atomicMin(&a.mm_acc[0], s_mm[0]);
-        if (s_mm[1] != 0ull) atomicMax(&a.mm_acc[1], s_mm[1]);
+        unsigned int base = incl - run;                                       // sum of the cells below this thread's first
+        for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            s_pre[tid * kPer + k] = base;
+            base += v[k];
+        }
+        if (tid == kThreads - 1) s_pre[kThreads * kPer] = base;
+        lds_barrier();
+        if (seen != la->seq) {
+            // (never in practice: workgroup 0 published the number tens of microseconds ago)
+            while (__hip_atomic_load(la->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != la->seq) __builtin_amdgcn_s_sleep(8);
+        }
+        const int sp0 = a.cells - 2, sp1 = a.cells - 1;                       // -inf / NaN dB (colour 0, bin 0); +inf dB (last colour, bin 0)
+        const unsigned int n0 = s_pre[sp0 + 1] - s_pre[sp0], n1 = s_pre[sp1 + 1] - s_pre[sp1];
+        unsigned long long *const out_c = la->out_c, *const out_cb = la->out_cb;
+        if (tid < a.lut_len && out_c) {
+            const unsigned int cnt = s_pre[cg_hi] - s_pre[cg_lo] + (tid == 0 ? n0 : 0u) + (tid == a.lut_len - 1 ? n1 : 0u);
+            if (cnt) atomicAdd(&out_c[tid], (unsigned long long)cnt);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int gi = tid + u * kThreads;
+            if (gi < SP_CB_HIST_SIZE && out_cb) {
+                const unsigned int cnt = s_pre[l_hi[u]] - s_pre[l_lo[u]] + (gi == 0 ? n0 + n1 : 0u);
+                if (cnt) atomicAdd(&out_cb[gi], (unsigned long long)cnt);
+            }
+        }
+        double *const out_mm = la->out_minmax;
+        if (tid < 2 && out_mm) {
+            // (the side outputs' folds are two barriers back)
+            typedef __attribute__((address_space(1))) double *GlobalF64;
+            if (tid == 0) __builtin_amdgcn_global_atomic_fmin_f64((GlobalF64)&out_mm[0], s_red[0]);
+            else __builtin_amdgcn_global_atomic_fmax_f64((GlobalF64)&out_mm[1], s_red[1]);
+        }
     }
 }
 

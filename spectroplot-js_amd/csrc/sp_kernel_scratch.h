@@ -202,28 +202,12 @@ struct FinishArgs {
     uint8_t *gauge_mins, *gauge_maxs, *gauge_amps;
     unsigned long long *mm_acc;   // [2] bit patterns of min / max |X|^2 over all frames; reset to {+inf, 0} here
     double *out_minmax;       // [2] or nullptr
-    // histograms: the frame-loop kernels add into context-owned accumulators (zero before and after every launch);
+    // histograms: the scratch kernel adds into context-owned accumulators (zero before and after every request);
     // this kernel moves them to the caller's arrays, so a reply always holds the counts of its own request
     int32_t lut_len;
     unsigned long long *acc_c, *acc_cb;
     unsigned long long *out_c, *out_cb;   // or nullptr
-    // k_frames: merged cells (sp_host.h Thresholds) instead of the two accumulators.  cell_acc is this launch's buffer,
-    // cell_clear the other one of the pair, which the NEXT launch counts into: a cell is read by two threads here (its colour
-    // index and its level), so the buffer that is read cannot be the one that is zeroed.
-    const unsigned long long *cell_acc;
-    unsigned long long *cell_clear;
-    const uint16_t *cell_g, *cell_l;
-    int32_t cells, cells_cap, cell_copies;
-    int32_t gauge_block0;     // the first workgroup that serves frames: the ones before it only turn the cells into histograms
 };
-
-// store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
-__device__ inline uint8_t clamp_u8(double v)
-{
-    if (!(v > 0.0)) return 0;
-    if (v >= 255.0) return 255;
-    return (uint8_t)rint(v);
-}
 
 __device__ inline double centre_sample(int fmt, const spfmt::View &v, int64_t pos, int c)
 {
@@ -239,19 +223,16 @@ __device__ inline double centre_sample(int fmt, const spfmt::View &v, int64_t po
 
 constexpr int kFinishThreads = 256;
 
-// d = dBfs - gain of one |X|^2 value, the reference's operation order                     worker.js:100,124-125
-__device__ inline double d_of_abs2(double abs2, double block_norm_db, double gain) { return (5 * spjs::log10(abs2) + block_norm_db + gain) - gain; }
-
-// Grid: gauge_block0 + 3 * ceil(width / kFinishThreads) workgroups (at least enough threads for the histograms).  The three
-// software log10 evaluations a frame needs are independent, so they run in different workgroups (role = block % 3) instead of
-// as one long dependent chain per thread; with merged cells the workgroups that build the histograms (loads, a scan) serve no
-// frames, so the kernel's two dependent chains run side by side.
+// The side outputs behind the scratch kernel (k_frames produces its own, sp_kernel_frames.h).
+// Grid: 3 * ceil(width / kFinishThreads) workgroups (at least enough threads for the histograms) + 1.  The three software log10
+// evaluations a frame needs are independent, so they run in different workgroups (role = block % 3) instead of as one long
+// dependent chain per thread.
 __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishArgs a)
 {
-    const int fb = (int)blockIdx.x - a.gauge_block0;
+    const int fb = (int)blockIdx.x;
     const int role = fb % 3;
     const int x = (fb / 3) * kFinishThreads + threadIdx.x;
-    if (fb >= 0 && x < a.width) {
+    if (x < a.width) {
         // d is monotone in abs2, so the frame's extreme d values come from its extreme abs2 values
         if (role == 0) {
             if (a.gauge_mins) {
@@ -275,73 +256,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_frames(const FinishAr
             a.gauge_amps[x] = clamp_u8(0.5 + (a.range + amp) * 256 / a.range);
         }
     }
-    if (a.cell_acc) {
-        // merged cells -> the two histograms: every count is a difference of two prefix sums over the cells.  The workgroups that
-        // own histogram outputs (the first few) build the prefix in LDS: 8 consecutive cells per thread, then a scan of the 256
-        // partial sums.
-        const int gi = blockIdx.x * kFinishThreads + threadIdx.x;
-        constexpr int kPer = 8;                                          // 256 threads x 8 >= the largest cell count
-        __shared__ unsigned long long s_pre[kFinishThreads * kPer + 1];
-        __shared__ unsigned long long s_part[kFinishThreads];
-        const bool owner = blockIdx.x * kFinishThreads < (a.lut_len > SP_CB_HIST_SIZE ? a.lut_len : SP_CB_HIST_SIZE);
-        if (owner) {
-            // the XCD copies of a cell are summed with coalesced loads (thread t takes cells t, t + 256, ...), then every thread picks
-            // up its 8 consecutive cells from LDS
-            // (every load of the thread is issued before the first sum: one memory latency instead of one per 256 cells)
-            constexpr int kCopies = 8;
-            // (the cell ranges of this thread's two outputs ride in the same batch: read after the scan they were a second latency)
-            const int gi_c = gi < a.lut_len ? gi : 0, l_cb = gi < SP_CB_HIST_SIZE ? SP_CB_HIST_SIZE - 1 - gi : 0;   // bin gi counts level 999 - gi
-            const int g_lo = a.cell_g[gi_c], g_hi = a.cell_g[gi_c + 1], l_lo = a.cell_l[l_cb], l_hi = a.cell_l[l_cb + 1];
-            unsigned long long part[kPer][kCopies];
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const int c = threadIdx.x + k * kFinishThreads;
-#pragma unroll
-                for (int x = 0; x < kCopies; x++)
-                    part[k][x] = (c < a.cells && x < a.cell_copies) ? a.cell_acc[(size_t)x * a.cells_cap + c] : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                unsigned long long sum = 0ull;
-#pragma unroll
-                for (int x = 0; x < kCopies; x++) sum += part[k][x];
-                s_pre[threadIdx.x + k * kFinishThreads] = sum;
-            }
-            __syncthreads();
-            unsigned long long v[kPer], run = 0;
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                v[k] = s_pre[threadIdx.x * kPer + k];
-                run += v[k];
-            }
-            // inclusive scan of the 256 partial sums: inside each wave with shuffles, the four wave totals through LDS
-            unsigned long long incl = run;
-            const int ln = threadIdx.x & 63;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned long long up = __shfl_up(incl, d, 64);
-                if (ln >= d) incl += up;
-            }
-            __syncthreads();                                              // every thread has read its cells from s_pre
-            if (ln == 63) s_part[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            unsigned long long below = 0ull;
-            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) below += s_part[w];
-            unsigned long long base = below + incl - run;                 // sum of the cells below this thread's first
-#pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                s_pre[threadIdx.x * kPer + k] = base;                     // s_pre[c] = sum of cells [0, c)
-                base += v[k];
-            }
-            if (threadIdx.x == kFinishThreads - 1) s_pre[kFinishThreads * kPer] = base;
-            __syncthreads();
-            const int sp0 = a.cells - 2, sp1 = a.cells - 1;
-            const unsigned long long n0 = s_pre[sp0 + 1] - s_pre[sp0], n1 = s_pre[sp1 + 1] - s_pre[sp1];
-            if (gi < a.lut_len && a.out_c) a.out_c[gi] = s_pre[g_hi] - s_pre[g_lo] + (gi == 0 ? n0 : 0ull) + (gi == a.lut_len - 1 ? n1 : 0ull);
-            if (gi < SP_CB_HIST_SIZE && a.out_cb) a.out_cb[gi] = s_pre[l_hi] - s_pre[l_lo] + (gi == 0 ? n0 + n1 : 0ull);
-        }
-        if (gi < a.cells_cap * a.cell_copies) a.cell_clear[gi] = 0ull;   // the whole buffer: the next plan may use more cells than this one
-    } else {
+    {
         // histograms: accumulators -> reply, accumulators back to zero
         const int gi = blockIdx.x * kFinishThreads + threadIdx.x;
         if (gi < a.lut_len) {

@@ -35,10 +35,30 @@ struct FrameArgs {
     double *frame_max;           // [width] max over the frame of abs2 (NaN ignored), 0 if none
     unsigned long long *mm_acc;  // [2] bit patterns of the min / max of abs2 over all frames ({+inf, 0} before every launch)
     double *scratch;             // scratch kernel only: gridDim.x * 2 * n doubles
-    unsigned long long *cell_acc;   // k_frames: [8][cells_cap] merged-cell accumulators, one copy per XCD (zero before every launch)
-    int32_t cells, cells_cap;
+    int32_t cells;               // k_frames: merged histogram cells in use (sp_host.h Thresholds)
     int32_t rgba_fast;           // rgba 16-byte aligned, width a multiple of 4 and < 2^24, image below 4 GiB
+    // k_frames produces the request's side outputs itself (the scratch kernel leaves them to k_finish_frames): gauges per group of
+    // frames; every workgroup adds its share of the histograms and of the dBfs range to the reply                worker.js:124-155
+    int32_t first;               // this launch starts its request (sp_render's chunks: only the first one does): workgroup 0 clears the reply
+    uint32_t seq;                // the request's number (never 0) ...
+    unsigned int *flag;          // ... which workgroup 0 stores here once the reply's histograms are zero and its range (0, -200)
+    uint8_t *gauge_mins, *gauge_maxs, *gauge_amps;   // [width] each, or nullptr
+    double block_norm_db, gain, range;
+    unsigned long long *out_c, *out_cb;              // the reply's histograms (device memory), or nullptr
+    double *out_minmax;          // [2] or nullptr
+    const uint16_t *cell_g, *cell_l;                 // merged-cell ranges per colour index / level (sp_host.h Thresholds)
 };
+
+// store into a Uint8ClampedArray: round half to even, clamp, NaN -> 0
+__device__ inline uint8_t clamp_u8(double v)
+{
+    if (!(v > 0.0)) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)rint(v);
+}
+
+// d = dBfs - gain of one |X|^2 value, the reference's operation order                     worker.js:100,124-125
+__device__ inline double d_of_abs2(double abs2, double block_norm_db, double gain) { return (5 * spjs::log10(abs2) + block_norm_db + gain) - gain; }
 
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
 __host__ __device__ inline int32_t frame_start(double stride, int32_t x) { return spjs::to_int32(0.5 + stride * (double)x); }
