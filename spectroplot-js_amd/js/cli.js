@@ -10,8 +10,9 @@
  *
  * The format defaults to the file extension (lib/parseFreqRate.js:58-70), the worker count to the number of visible GPUs.
  * Output: binary PPM (P6, alpha dropped) or, with --out *.rgba, the raw RGBA bytes exactly as the reference's canvas holds them.
- * --full composes the plot the reference shows around the spectrogram as far as it can be drawn exactly (js/raster.js): amplitude and
- * min/max gauge strips above it, the dB scale (colour ramp, tick marks) to its right; labels and histogram outlines need a canvas.
+ * --full composes the plot the reference shows around the spectrogram (js/raster.js): amplitude and min/max gauge strips above it, to
+ * its right the dB scale (colour ramp, tick marks) with the two histogram outlines over it (filled and stroked without anti-aliasing);
+ * only the text labels need a canvas.
  */
 const fs = require('fs')
 const { renderSliced, parseFormat, parseFreqRate, HipWorker, composePlot, cmapByName } = require('./index.js')

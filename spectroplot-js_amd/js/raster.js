@@ -9,9 +9,14 @@
  *   putImageData(image, x, y)          copies pixels, no blending (canvas semantics)
  *   fillRect(x, y, w, h, fillStyle)    integer-aligned rectangles with opaque or translucent CSS colours (#rgb, #rrggbb, rgb(), rgba());
  *                                      source-over blending in 8-bit, as a canvas without colour management does it
+ *   beginPath / moveTo / lineTo / fill(fillStyle) / stroke(strokeStyle, lineWidth)
+ *                                      the path subset of the histogram outlines (lib/spectroplot.js:686-757): polygons filled by
+ *                                      scanline under the non-zero winding rule, a pixel belonging to the shape when its centre does
+ *                                      (no anti-aliasing); strokes as the set of pixel centres within lineWidth / 2 of a segment
  * Rectangles whose edges fall between pixels (a dB tick at a fractional y) are drawn with coverage-weighted source-over, which a
- * browser's anti-aliasing approximates but does not promise: such pixels are not pinned.  Text (`fillText`) and the histogram
- * outlines (`beginPath` / `lineTo` / `fill` / `stroke`: anti-aliased polygons) are skipped by replay() and stay command lists.
+ * browser's anti-aliasing approximates but does not promise: such pixels are not pinned, and neither are the pixels a polygon's edge
+ * or a stroke passes through (a browser shades them by coverage; here they are in or out).  The interior and the exterior are exact.
+ * Text (`fillText`) is skipped by replay() and stays a command list: fonts are the caller's.
  */
 
 function parseColor(style) {
@@ -70,13 +75,72 @@ class Surface {
         }
     }
 
-    /** Replays a consumers.js command list at an offset; returns the commands it left out (text, paths). */
+    // ---- paths: the subset drawHistograms uses (one sub-path of straight segments, filled, then stroked) ----
+    beginPath() { this.path = [] }
+    moveTo(x, y) { (this.path = this.path || []).push([[x, y]]) }
+    lineTo(x, y) {
+        if (!this.path || !this.path.length) return this.moveTo(x, y)           // canvas: lineTo without a current point acts as moveTo
+        this.path[this.path.length - 1].push([x, y])
+    }
+
+    /** fill(): every sub-path closed implicitly; non-zero winding; a pixel is inside when its centre is. */
+    fill(style) {
+        const c = parseColor(style), subs = (this.path || []).filter(p => p.length > 2)
+        if (!subs.length) return
+        let y0 = Infinity, y1 = -Infinity
+        for (const p of subs) for (const [, y] of p) { if (y < y0) y0 = y; if (y > y1) y1 = y }
+        for (let py = Math.max(0, Math.floor(y0)); py < Math.min(this.height, Math.ceil(y1)); py++) {
+            const yc = py + 0.5, hits = []
+            for (const p of subs) {
+                for (let i = 0; i < p.length; i++) {
+                    const [ax, ay] = p[i], [bx, by] = p[(i + 1) % p.length]
+                    if ((ay <= yc) === (by <= yc)) continue                      // the edge does not cross this row of centres
+                    hits.push([ax + (yc - ay) * (bx - ax) / (by - ay), by > ay ? 1 : -1])
+                }
+            }
+            hits.sort((u, v) => u[0] - v[0])
+            let wind = 0
+            for (let k = 0; k + 1 < hits.length; k++) {
+                wind += hits[k][1]
+                if (!wind) continue
+                // centres px + 0.5 in [x_k, x_k+1)
+                for (let px = Math.max(0, Math.ceil(hits[k][0] - 0.5)); px < Math.min(this.width, Math.ceil(hits[k + 1][0] - 0.5)); px++) this._blend(px, py, c, 1)
+            }
+        }
+    }
+
+    /** stroke(): every pixel whose centre lies within lineWidth / 2 of a segment of the path, once. */
+    stroke(style, lineWidth) {
+        const c = parseColor(style), hw = (lineWidth === undefined ? 1 : lineWidth) / 2, seen = new Set()
+        for (const p of this.path || []) {
+            for (let i = 0; i + 1 < p.length; i++) {
+                const [ax, ay] = p[i], [bx, by] = p[i + 1], dx = bx - ax, dy = by - ay, len2 = dx * dx + dy * dy
+                for (let py = Math.max(0, Math.floor(Math.min(ay, by) - hw)); py <= Math.min(this.height - 1, Math.ceil(Math.max(ay, by) + hw)); py++) {
+                    for (let px = Math.max(0, Math.floor(Math.min(ax, bx) - hw)); px <= Math.min(this.width - 1, Math.ceil(Math.max(ax, bx) + hw)); px++) {
+                        const qx = px + 0.5 - ax, qy = py + 0.5 - ay
+                        const t = len2 ? Math.min(1, Math.max(0, (qx * dx + qy * dy) / len2)) : 0
+                        const ex = qx - t * dx, ey = qy - t * dy
+                        if (ex * ex + ey * ey > hw * hw || seen.has(py * this.width + px)) continue
+                        seen.add(py * this.width + px)
+                        this._blend(px, py, c, 1)
+                    }
+                }
+            }
+        }
+    }
+
+    /** Replays a consumers.js command list at an offset; returns the commands it left out (text). */
     replay(calls, dx, dy) {
         dx = dx || 0; dy = dy || 0
         const skipped = []
         for (const c of calls) {
             if (c[0] === 'fillRect') this.fillRect(c[1] + dx, c[2] + dy, c[3], c[4], c[5])
             else if (c[0] === 'putImageData') this.putImageData(c[5], c[1] + dx, c[2] + dy)
+            else if (c[0] === 'beginPath') this.beginPath()
+            else if (c[0] === 'moveTo') this.moveTo(c[1] + dx, c[2] + dy)
+            else if (c[0] === 'lineTo') this.lineTo(c[1] + dx, c[2] + dy)
+            else if (c[0] === 'fill') this.fill(c[1])
+            else if (c[0] === 'stroke') this.stroke(c[1], c[2])
             else skipped.push(c)
         }
         return skipped
@@ -98,8 +162,9 @@ class Surface {
  * One image with everything the reference shows around a spectrogram that can be drawn exactly: amplitude gauge strip, min/max gauge
  * strip, the spectrogram, and to its right the dB scale (colour ramp + tick marks).  The layout is this module's (the reference's is
  * CSS): rows = ampHeight | minmaxHeight | image height + timeHeight, columns = image width | dbfsWidth + histWidth.
+ * The two histogram outlines (drawHistograms, lib/spectroplot.js:686-757) are drawn over the scale as the reference draws them.
  * `r` is renderSliced's result, `o` = {cmap (array path: the message's cmap with forced ends), gain, range, n, waterfall?, ampHeight?,
- * minmaxHeight?, histWidth?, opts?, theme?}.  Returns {surface, skipped: the text / outline commands a canvas would still have to draw}.
+ * minmaxHeight?, histWidth?, opts?, theme?}.  Returns {surface, skipped: the text commands a canvas would still have to draw}.
  */
 function composePlot(r, o) {
     const { rampMarkers, histogramOutlines, gaugeColumns } = require('./consumers.js')
@@ -118,8 +183,8 @@ function composePlot(r, o) {
     }
     s.putImageData({ data: r.data, width: r.width, height: r.height }, 0, gaugeRows)
     skipped = skipped.concat(s.replay(ramp.calls, r.width, gaugeRows))
-    skipped = skipped.concat(histogramOutlines({ c_hist: r.c_hist, cB_hist: r.cB_hist, cmapLength: o.cmap.length, height: scaleRows,
-        histWidth: o.histWidth, opts: o.opts, theme: o.theme }).map(c => c.slice()))
+    skipped = skipped.concat(s.replay(histogramOutlines({ c_hist: r.c_hist, cB_hist: r.cB_hist, cmapLength: o.cmap.length, height: scaleRows,
+        histWidth: o.histWidth, opts: o.opts, theme: o.theme }), r.width, gaugeRows))
     return { surface: s, skipped, origin: { image: [0, gaugeRows], scale: [r.width, gaugeRows] } }
 }
 

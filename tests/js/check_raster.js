@@ -5,7 +5,11 @@
  *     against "the last rectangle that covers a pixel wins" evaluated pixel by pixel;
  *   - the colour ramp image and tick rectangles of the reference's drawColorRamp (tests/golden/consumers.json): the ramp pixels are the
  *     recorded image's, integer-aligned ticks are theme.rampFill; text commands come back as skipped;
- *   - translucent fills blend source-over; composePlot puts strips, gauges and scale where its layout says.
+ *   - the two histogram outlines of the reference's drawHistograms (tests/golden/consumers.json `hist`: its own moveTo / lineTo / fill /
+ *     stroke calls): every pixel that lies wholly inside an outline carries that outline's fill, every pixel wholly outside both and
+ *     clear of the strokes is untouched - decided by an independent model (the outline is a function x(y), piecewise linear between
+ *     rows), not by the scanline code; pixels an edge or a stroke passes through are a browser's anti-aliasing and are not pinned;
+ *   - translucent fills blend source-over; composePlot puts strips, gauges, scale and histograms where its layout says.
  */
 const fs = require('fs'), path = require('path'), assert = require('assert')
 const root = path.join(__dirname, '..', '..')
@@ -61,6 +65,62 @@ for (const g of cons) {
 }
 assert(ticks > 10, 'ticks checked: ' + ticks)
 
+// histogram outlines: the reference's recorded path calls on a Surface, against the per-pixel model
+let inside = 0, outside = 0
+for (const g of cons) {
+    const s = new Surface(g.canvas.width, g.canvas.height, '#fff')
+    assert.deepStrictEqual(s.replay(g.hist), [], g.name + ': every outline call is drawn')
+    // split the call list into its outlines: [vertices, fill style, stroke style, line width]
+    const shapes = []
+    let cur = null
+    for (const c of g.hist) {
+        if (c[0] === 'beginPath') cur = { pts: [] }
+        else if (c[0] === 'moveTo' || c[0] === 'lineTo') cur.pts.push([c[1], c[2]])
+        else if (c[0] === 'fill') cur.fill = c[1]
+        else if (c[0] === 'stroke') { cur.stroke = c[1]; cur.line = c[2]; shapes.push(cur) }
+    }
+    if (!g.hist.length) continue                                                // histWidth 0: the reference draws none
+    assert.strictEqual(shapes.length, 2, g.name + ': two outlines')
+    // an outline runs from (left, top) along (left + x_r, top + r), r = 0 .. rows-1, to (left, top + rows) and closes: between two rows its
+    // right edge is the segment x_r .. x_r+1, its left edge the line x = left
+    const model = shapes.map(sh => {
+        const left = sh.pts[0][0], top = sh.pts[0][1], xs = sh.pts.slice(1, -1).map(p => p[0]), rows = xs.length
+        assert.strictEqual(sh.pts[sh.pts.length - 1][1], top + rows)
+        const xAt = y => {                                                      // right edge at height y (top <= y <= top + rows)
+            const r = y - top
+            if (r >= rows - 1) return r >= rows ? left : xs[rows - 1] + (left - xs[rows - 1]) * (r - (rows - 1))   // the closing segment to (left, top + rows)
+            const i = Math.floor(r)
+            return xs[i] + (xs[i + 1] - xs[i]) * (r - i)
+        }
+        return { left, top, rows, xAt, half: sh.line / 2, fill: parseColor(sh.fill) }
+    })
+    const blend = (dst, c) => { const a = c[3] / 255; return dst.map((v, k) => k < 3 ? Math.round(c[k] * a + v * (1 - a)) : 255) }
+    for (let y = 0; y < s.height; y++) {
+        for (let x = 0; x < s.width; x++) {
+            let want = [255, 255, 255, 255], decided = true
+            for (const m of model) {
+                if (y < m.top - 2 || y >= m.top + m.rows + 2) continue                            // clear of this outline, strokes included
+                // the right edge over this pixel row and a stroke's reach either side of it (piecewise linear: extremes at row boundaries)
+                const margin = m.half + 1
+                let lo = Infinity, hi = -Infinity
+                for (let yy = Math.floor(y - margin); yy <= Math.ceil(y + 1 + margin); yy++) {
+                    const xe = m.xAt(Math.max(m.top, Math.min(m.top + m.rows, yy)))
+                    lo = Math.min(lo, xe); hi = Math.max(hi, xe)
+                }
+                if (y >= m.top + margin && y + 1 <= m.top + m.rows - margin && x >= m.left + margin && x + 1 <= lo - margin) want = blend(want, m.fill)   // wholly inside, clear of the stroke
+                else if (x >= hi + margin || x + 1 <= m.left - margin) continue                  // wholly outside
+                else decided = false
+            }
+            if (!decided) continue
+            const o = 4 * (y * s.width + x)
+            assert.deepStrictEqual(Array.from(s.data.subarray(o, o + 4)), want, `${g.name}: pixel (${x}, ${y})`)
+            if (want[0] !== 255 || want[1] !== 255) inside++
+            else outside++
+        }
+    }
+}
+assert(inside > 5000 && outside > 50000, `histogram pixels checked: ${inside} inside, ${outside} outside`)
+
 // source-over blending of a translucent fill, 8-bit
 const b = new Surface(2, 1, '#fff')
 b.fillRect(0, 0, 1, 1, 'rgba(187,0,187,0.2)')
@@ -82,7 +142,12 @@ assert.strictEqual(S.width, width + 160)
 for (let y = 0; y < n; y++) for (let x = 0; x < width; x++) assert.strictEqual(S.data[4 * ((y + 12) * S.width + x)], data[4 * (y * width + x)], 'image pixel')
 assert.deepStrictEqual(Array.from(S.data.subarray(0, 4)), [127, 127, 127, 255])                    // amp gauge column 0: grey 255 - 128, full height ~~(255 * 4 / 256) = 3
 assert.deepStrictEqual(Array.from(S.data.subarray(4 * 3 * S.width, 4 * 3 * S.width + 4)), [255, 255, 255, 255])   // row 3: past the bar, page white
-assert(plot.skipped.some(c => c[0] === 'fillText') && plot.skipped.some(c => c[0] === 'lineTo'))
+assert(plot.skipped.length > 0 && plot.skipped.every(c => c[0] === 'fillText'), 'composePlot draws everything but text')
+// flat histograms: both outlines span the full histogram width, so a pixel well inside carries both translucent fills over the page white
+{
+    const px = plot.origin.scale[0] + 55 + 50, py = plot.origin.scale[1] + 10 + 4, o = 4 * (py * S.width + px)
+    assert.deepStrictEqual(Array.from(S.data.subarray(o, o + 4)), [223, 194, 223, 255], 'histogram fills in the composed plot')
+}
 const ppm = S.toPPM()
 assert.strictEqual(ppm.slice(0, 2).toString(), 'P6')
-console.log(`raster checks ok (${rects} gauge rectangles of the reference replayed pixel for pixel, ${ticks} ticks)`)
+console.log(`raster checks ok (${rects} gauge rectangles of the reference replayed pixel for pixel, ${ticks} ticks, ${inside} + ${outside} histogram pixels)`)
