@@ -98,6 +98,10 @@ __host__ __device__ inline int group_frames_for(int n, int want)
     return f;
 }
 
+// n <= 1024: a group's side outputs are evaluated behind the SECOND barrier of the following group's first frame, which takes a second
+// set of frame-extreme slots (n >= 2048 has no LDS left for one: they are evaluated behind the first barrier there)
+__host__ __device__ inline constexpr bool late_side_outputs(int n) { return n <= 1024; }
+
 struct Layout {
     int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_amp, off_win, total;
 };
@@ -111,7 +115,7 @@ __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames)
     l.off_gedge = o;  o += lut_len * 8;                          // exact edge tables (read by the few lanes the f32 test sends there)
     l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
     o = (o + 15) & ~15;
-    l.off_mm = o;     o += group_frames * mm_slots(n) * 2 * 8;
+    l.off_mm = o;     o += (late_side_outputs(n) ? 2 : 1) * group_frames * mm_slots(n) * 2 * 8;   // frame extremes (n <= 1024: by group parity)
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
     l.off_lut = o;    o += lut_len * 4;
     l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
@@ -148,6 +152,21 @@ __device__ inline void lds_min_f64(double *p, double v)
 __device__ inline void lds_max_f64(double *p, double v)
 {
     asm volatile("ds_max_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)p), "v"(v) : "memory");
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave in the VALU: row shifts, then the two row broadcasts of the GFX9 family (a shuffle
+// scan is six dependent trips through the LDS crossbar).
+__device__ inline unsigned wave_scan_u32(unsigned x)
+{
+#define SP_DPP_ADD(ctrl, rows) x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false);
+    SP_DPP_ADD(0x111, 0xf)   // row_shr:1
+    SP_DPP_ADD(0x112, 0xf)   // row_shr:2
+    SP_DPP_ADD(0x114, 0xf)   // row_shr:4
+    SP_DPP_ADD(0x118, 0xf)   // row_shr:8
+    SP_DPP_ADD(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
+    SP_DPP_ADD(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
+#undef SP_DPP_ADD
+    return x;
 }
 
 // 16-byte non-temporal store (dst is 16-byte aligned)
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     constexpr bool WIN_LDS = lds_win_in_lds(N);   // taper in LDS for n <= 1024, in registers for the whole launch above
     double *s_win = (double *)(smem + lay.off_win);
     constexpr int MMS = mm_slots(N);
+    constexpr bool LATE_SIDE = late_side_outputs(N);
     {
         // tables -> LDS: every global load is issued before the first LDS store (one memory latency for the prologue)
         constexpr int WINK = WIN_LDS ? (N + kThreads - 1) / kThreads : 1;
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
         if (tid < 8) s_done[tid] = 0;
         if (tid < 2) s_red[tid] = tid ? -200.0 : 0.0;                             // worker.js:35-36
-        for (int i = tid; i < group_frames * MMS; i += kThreads) {
+        for (int i = tid; i < (LATE_SIDE ? 2 : 1) * group_frames * MMS; i += kThreads) {
             s_mm[2 * i] = 0x7ff0000000000000ull;
             s_mm[2 * i + 1] = 0ull;
         }
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             unsigned long long ext = role ? 0ull : 0x7ff0000000000000ull;
 #pragma unroll
             for (int k = 0; k < MMS; k++) {
-                unsigned long long *slot = s_mm + 2 * (f * MMS + k) + role;
+                unsigned long long *slot = s_mm + 2 * (((LATE_SIDE ? par : 0) * group_frames + f) * MMS + k) + role;
                 const unsigned long long v = *slot;
                 ext = role ? (v > ext ? v : ext) : (v < ext ? v : ext);
                 *slot = role ? 0ull : 0x7ff0000000000000ull;
@@ -647,7 +667,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             // the previous group's write-out goes in two slices around this frame's passes, so that its stores drain while the SIMDs compute
             if (drain_x0 >= 0) {
                 lds_barrier();
-                side_outputs(drain_x0, gpar ^ 1);
+                if constexpr (!LATE_SIDE) side_outputs(drain_x0, gpar ^ 1);
                 drain(drain_x0, 0, 2);
             }
             // ---- first pass: literal twiddles ------------------------------------------------------------------------------
@@ -714,16 +734,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     }
                     if constexpr (STAGED) fft_pass_staged<WS2, 9, E2, TWMAX>(re, im, tl, s_tw, tw);
                     else fft_pass<WS2, 9, E2>(re, im, tw2);
-                    if constexpr (NPASS >= 4) {
-                        constexpr int WS3 = LOG2N - 4;
-                        double *const b3 = xbuf + pad_idx(win_pos(tl, 0, WS3));
-                        PassTw<WS3, 13, LOG2N, TWMAX> tw3;
-                        load_pass_tw(tw3, tl, s_tw, tw);
-                        exchange<WS2, WS3, BLOCK_SYNC, false>(re, b2, b3, meet);
-                        exchange<WS2, WS3, BLOCK_SYNC, true>(im, b2, b3, meet);
-                        exchange_wait(re, im);
-                        fft_pass<WS3, 13, LOG2N>(re, im, tw3);
-                    }
+                    static_assert(NPASS <= 3, "four passes (n = 8192) take the register-transpose branch above");
                 }
             }
             // now register e of thread tl holds bin i = tl + e*T
@@ -773,6 +784,10 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             if (drain_x0 >= 0) {
                 drain(drain_x0, 1, 2);
                 lds_barrier();
+                // The previous group's side outputs, here: the two waves that evaluate them (a software log10, ~1 us) next meet the
+                // others at the start of the following group, where the first waves of the SIMDs arrive early anyway; in front of this
+                // barrier they held everybody up.  (The frames' extremes and centre samples are kept per group parity for it.)
+                if constexpr (LATE_SIDE) side_outputs(drain_x0, gpar ^ 1);
                 drain_x0 = -1;
             }
             // ---- |X|^2 -> colour index, centi-bel level ---------------------------------------------------------------------
@@ -872,7 +887,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 }
                 const double mn = min_raw(min_raw(mn4[0], mn4[1]), min_raw(mn4[2], mn4[3]));
                 const double mx = max_raw(max_raw(mx4[0], mx4[1]), max_raw(mx4[2], mx4[3]));
-                unsigned long long *slot = s_mm + 2 * (fr * MMS + (tl & (MMS - 1)));
+                unsigned long long *slot = s_mm + 2 * (((LATE_SIDE ? gpar : 0) * group_frames + fr) * MMS + (tl & (MMS - 1)));
                 atomicMin(slot, (unsigned long long)__double_as_longlong(mn));
                 atomicMax(slot + 1, (unsigned long long)__double_as_longlong(mx));
             }
@@ -918,10 +933,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         drain_rows(drain_x0, 0, 1, half * (group_frames / 2), group_frames / 2, half * (kThreads / 2), kThreads / 2, true);
     }
     lds_barrier();
-    if (drain_x0 >= 0) {
-        side_outputs(drain_x0, gpar ^ 1);
-        if (!(HALVES && a.rgba)) drain(drain_x0, 0, 1);
-    }
+    if (drain_x0 >= 0 && !(HALVES && a.rgba)) drain(drain_x0, 0, 1);
     // ---- the workgroup's share of the request's histograms and dBfs range (worker.js:105-113, 124-125, 140-155) ----------------------
     // No workgroup finishes for the others (that costs the last one three dependent trips to memory, 6 us): every workgroup turns its
     // own merged cells into histogram counts and adds them to the reply itself, with fire-and-forget atomics the launch's end waits
@@ -942,16 +954,17 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             v[k] = c < a.cells ? s_cells[c] : 0u;
             run += v[k];
         }
-        unsigned int incl = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
+        const unsigned int incl = wave_scan_u32(run);
         if (lane == 63) s_part[tid >> 6] = incl;
         lds_barrier();
         unsigned int base = incl - run;                                       // sum of the cells below this thread's first
-        for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
+        {
+            const uint4 p0 = *(const uint4 *)s_part, p1 = *(const uint4 *)(s_part + 4);   // (one batch of reads, not one per wave below)
+            const unsigned int part[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            const int wave = tid >> 6;
+#pragma unroll
+            for (int w = 0; w < 7; w++) base += w < wave ? part[w] : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
             s_pre[tid * kPer + k] = base;
@@ -978,9 +991,12 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 if (cnt) atomicAdd(&out_cb[gi], (unsigned long long)cnt);
             }
         }
+        // The last group's gauges come behind the adds (two waves, one software log10: ~1 us during which everybody's adds and stores
+        // are on their way), and behind them the workgroup's share of the dBfs range.
+        if (drain_x0 >= 0) side_outputs(drain_x0, gpar ^ 1);
+        lds_barrier();
         double *const out_mm = la->out_minmax;
         if (tid < 2 && out_mm) {
-            // (the side outputs' folds are two barriers back)
             typedef __attribute__((address_space(1))) double *GlobalF64;
             if (tid == 0) __builtin_amdgcn_global_atomic_fmin_f64((GlobalF64)&out_mm[0], s_red[0]);
             else __builtin_amdgcn_global_atomic_fmax_f64((GlobalF64)&out_mm[1], s_red[1]);

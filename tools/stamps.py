@@ -25,12 +25,12 @@ for _ in range(300):
     plan.execute(d_in, S * sw, W, *ptrs)
 ctx.synchronize()
 waves = 8 if n > 1024 else int(os.environ.get("SP_WAVES", "8"))
-cnt = 256 * waves * 20
+cnt = 256 * waves * 24
 buf = (ctypes.c_ulonglong * cnt)()
 lib = ctx.lib.L
 lib.sp_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 assert lib.sp_debug_read_stamps(ctx.h, buf, cnt) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(256, waves, 20).astype(np.float64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(256, waves, 24).astype(np.float64)
 names = ["head+decode", "pass1+xch1(+drain0)", "pass2+xch2", "pass3", "drain+barrier", "epilogue", "loop total", "start clock"]
 tot = a[:, :, 6].mean()
 print("%s: mean cycles per wave over the frame loop (%d frames per wave): %.0f" % (cfg, W // (256 * waves), tot))
@@ -52,7 +52,8 @@ hw = a[:, :, 13].astype(np.int64)
 print("  SIMD of wave index 0..7 (workgroup 0, 1, 100):", [list((hw[b] >> 4) & 3) for b in (0, 1, 100)], " wave slot:", list(hw[0] & 15))
 simd = (hw >> 4) & 3
 print("  mean loop total by SIMD:", [round(float(a[:, :, 6][simd == q].mean())) for q in range(4)])
-for k, nm in ((12, "barrier after the loop"), (14, "last write-out issued"), (15, "barrier, extremes, outstanding memory ops")):
+for k, nm in ((12, "barrier after the loop"), (20, "last write-out issued (not by wave sets)"), (21, "cells -> prefix sums (two barriers)"),
+              (14, "adds issued, last side outputs, barrier"), (15, "range adds, outstanding memory ops")):
     print("  tail: %-42s %7.0f cycles (%.2f us)  by wave:" % (nm, a[:, :, k].mean(), a[:, :, k].mean() / ghz / 1e3), np.round(a[:, :, k].mean(axis=0)))
 st = a[:, :, 11]
 print("  wave start times: spread %.2f us over the launch; last wave end - first wave start = %.2f us"
