@@ -20,6 +20,8 @@
  *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
  *   sp_merge_replies         lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
  *   sp_place_strips          lib/spectroplot.js:1241-1244   the caller's putImageData of every slice's strip, on the device
+ *   sp_group_render          lib/spectroplot.js:1206-1244, lib/samples.js:253-258   the caller's sliced render: one slice per device, the
+ *                                                        strips gathered device to device (RCCL / peer copies), merged on the root
  *   sp_synth_*               (none)                     device-side synthetic I/Q for benchmarks
  *
  * The request fields are the reference message's (lib/spectroplot.js:1213-1226):
@@ -134,6 +136,8 @@ int sp_context_create(int32_t device, sp_context **ctx);
 void sp_context_destroy(sp_context *ctx);
 /* Uses an existing hipStream_t instead of the context's own (e.g. the caller's framework stream). NULL restores. */
 int sp_context_set_stream(sp_context *ctx, void *hip_stream);
+/* The stream a caller bound with sp_context_set_stream, NULL while the context uses its own (what to hand back to set_stream to restore). */
+int sp_context_get_stream(const sp_context *ctx, void **hip_stream);
 int sp_context_synchronize(sp_context *ctx);
 
 /*
@@ -197,6 +201,27 @@ int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int3
  */
 int sp_place_strips(sp_context *ctx, uint8_t *d_image, const uint8_t *d_strips, int32_t count, int32_t n, int32_t width,
                     int32_t slice_width, int32_t waterfall);
+/*
+ * The caller's sliced render from one process (lib/spectroplot.js:1206-1244): a group owns one context per listed device (a device may be
+ * listed more than once: every entry is a member with its own context and stream).  sp_group_render cuts the capture into
+ * sp_group_size() slices as SampleView.slice does (lib/samples.js:253-258), uploads slice r to member r and renders it there - all
+ * members at once - with sliceWidth = ~~(width / members) frames each; the strips and the slices' side outputs then travel to the root
+ * member's device (member 0) without visiting host memory: grouped ncclSend / ncclRecv (RCCL over xGMI; librccl is loaded at run time)
+ * when the members sit on distinct devices, peer copies otherwise or when SPECTROPLOT_HIP_NO_RCCL is set; there sp_merge_replies and
+ * sp_place_strips do the caller's merge, and the merged image returns in ONE copy.
+ * `reply` holds host pointers: rgba [4 * width * n] (columns beyond members * sliceWidth are zero, as the caller's canvas leaves them),
+ * c_hist / cb_hist / dbfs_minmax merged over the slices (starting from 0 and (0, -200), :1125-1126), gauge_* [width] with slice r's
+ * gauges at [r * sliceWidth, (r + 1) * sliceWidth).  Any may be NULL.  Plans are kept while the request's constants repeat.
+ * sp_group_transport names what moved the strips in the last render: "none" (one member), "rccl" or "peer".
+ */
+typedef struct sp_group sp_group;
+int sp_group_create(const int32_t *devices, int32_t count, sp_group **group);
+void sp_group_destroy(sp_group *group);
+int sp_group_size(const sp_group *group);
+int sp_group_render(sp_group *group, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+const char *sp_group_transport(const sp_group *group);
+const char *sp_group_last_error(const sp_group *group);
+
 /* Name of the kernel sp_plan_execute launches: "frames" (64 <= n <= 8192, LUT <= 256 entries) or "scratch_radix2" (everything else). */
 const char *sp_plan_kernel_name(const sp_plan *plan);
 /* Forces a kernel (tests compare the two device paths): 0 automatic, 1 scratch_radix2, 3 frames (2: removed, SP_ERR_UNSUPPORTED). */

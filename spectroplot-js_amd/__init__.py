@@ -8,9 +8,9 @@ and there is no CPU fallback: importing works anywhere, but every compute call n
 Load it with `importlib` (the directory name has a hyphen), e.g. `from __graft_entry__ import load_package`.
 """
 from . import binding  # noqa: F401
-from .binding import (Library, Context, Plan, SpectroplotError, FORMATS, lib_path, build_library,  # noqa: F401
+from .binding import (Library, Context, Plan, Group, SpectroplotError, FORMATS, lib_path, build_library,  # noqa: F401
                       parse_format, slice_bounds, window, twiddles)
 from .worker import HipWorker, render_sliced  # noqa: F401
 
-__all__ = ["Library", "Context", "Plan", "SpectroplotError", "FORMATS", "HipWorker", "render_sliced", "lib_path",
+__all__ = ["Library", "Context", "Plan", "Group", "SpectroplotError", "FORMATS", "HipWorker", "render_sliced", "lib_path",
            "build_library", "parse_format", "slice_bounds", "window", "twiddles"]

@@ -85,6 +85,7 @@ class Library:
         L.sp_context_destroy.argtypes = [vp]
         L.sp_context_destroy.restype = None
         L.sp_context_set_stream.argtypes = [vp, vp]
+        L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.sp_context_synchronize.argtypes = [vp]
         L.sp_render.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply)]
         L.sp_render_named.argtypes = [vp, C.POINTER(_NamedRequest), vp, sz, i32, C.POINTER(_Reply)]
@@ -108,6 +109,15 @@ class Library:
         L.sp_merge_replies.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_place_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
+        L.sp_group_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+        L.sp_group_destroy.argtypes = [vp]
+        L.sp_group_destroy.restype = None
+        L.sp_group_size.argtypes = [vp]
+        L.sp_group_render.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply)]
+        L.sp_group_transport.restype = C.c_char_p
+        L.sp_group_transport.argtypes = [vp]
+        L.sp_group_last_error.restype = C.c_char_p
+        L.sp_group_last_error.argtypes = [vp]
 
     @classmethod
     def get(cls):
@@ -204,6 +214,12 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._chk(self.lib.L.sp_context_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def get_stream(self):
+        """The stream handle bound with set_stream (0 while the context uses its own): what set_stream takes to restore it."""
+        s = C.c_void_p()
+        self._chk(self.lib.L.sp_context_get_stream(self.h, C.byref(s)))
+        return s.value or 0
 
     def synchronize(self):
         self._chk(self.lib.L.sp_context_synchronize(self.h))
@@ -339,3 +355,52 @@ class Plan:
         rep = _Reply(rgba or None, gauge_mins or None, gauge_maxs or None, gauge_amps or None, c_hist or None, cb_hist or None,
                      dbfs_minmax or None)
         self.ctx._chk(self.ctx.lib.L.sp_plan_execute(self.h, C.c_void_p(d_bytes), nbytes, int(width), C.byref(rep)))
+
+
+class Group:
+    """The caller's sliced render from one process (sp_group_*): one member context per listed device, slice r rendered on member r,
+    strips gathered device to device (RCCL or peer copies) and merged on the root (lib/spectroplot.js:1206-1244)."""
+
+    def __init__(self, devices):
+        self.lib = Library.get()
+        arr = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.sp_group_create(arr, len(devices), C.byref(h)))
+        self.h = h
+        self.size = len(devices)
+
+    def close(self):
+        if self.h:
+            self.lib.L.sp_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transport(self):
+        return self.lib.L.sp_group_transport(self.h).decode()
+
+    def render(self, fmt, data, n, windowc, block_norm, gain, rng, lut, width, channel_mode=False, waterfall=False):
+        """Same argument meaning as Context.render; the reply is the caller's MERGED result (`rgba` the whole image, histograms and
+        dBfs range over all slices, gauges with slice r's at [r * slice_width, (r + 1) * slice_width))."""
+        fid, _ = parse_format(fmt)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        req, keep = _make_request(fid, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)
+        W = int(width)
+        L = len(keep[1])
+        out = {"rgba": np.zeros(4 * max(W, 0) * n, np.uint8), "gauge_mins": np.zeros(max(W, 0), np.uint8),
+               "gauge_maxs": np.zeros(max(W, 0), np.uint8), "gauge_amps": np.zeros(max(W, 0), np.uint8),
+               "c_hist": np.zeros(L, np.uint64), "cB_hist": np.zeros(SP_CB_HIST_SIZE, np.uint64)}
+        mm = np.array([0.0, -200.0])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rep = _Reply(p(out["rgba"]), p(out["gauge_mins"]), p(out["gauge_maxs"]), p(out["gauge_amps"]), p(out["c_hist"]),
+                     p(out["cB_hist"]), p(mm))
+        status = self.lib.L.sp_group_render(self.h, C.byref(req), p(data), data.size, W, C.byref(rep))
+        if status:
+            raise SpectroplotError(status, self.lib.L.sp_group_last_error(self.h).decode() or self.lib.L.sp_status_string(status).decode())
+        out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])
+        out["slice_width"] = W // self.size
+        return out

@@ -348,6 +348,13 @@ extern "C" int sp_context_set_stream(sp_context *ctx, void *hip_stream)
     return SP_OK;
 }
 
+extern "C" int sp_context_get_stream(const sp_context *ctx, void **hip_stream)
+{
+    if (!ctx || !hip_stream) return SP_ERR_INVALID_ARG;
+    *hip_stream = ctx->stream == ctx->own_stream ? nullptr : (void *)ctx->stream;
+    return SP_OK;
+}
+
 extern "C" int sp_context_synchronize(sp_context *ctx)
 {
     if (!ctx) return SP_ERR_INVALID_ARG;

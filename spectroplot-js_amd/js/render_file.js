@@ -6,7 +6,7 @@
  * Un-rendered columns stay zero, as on the reference's canvas.
  */
 const path = require('path')
-const { HipWorker } = require('./hip_worker.js')
+const { HipWorker, packLut } = require('./hip_worker.js')
 
 function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node')) }
 
@@ -14,6 +14,11 @@ function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplo
  * With `byName: true`, `window` and `cmap` are option names (any spelling the reference's lookup accepts) and the slices go to the
  * workers as named requests (HipWorker.renderNamed -> sp_render_named): taper, block_norm and the end-forced colour map are evaluated
  * inside the library, once per worker while the names repeat.
+ * With `device: true` the whole sliced render is ONE native call (sp_group_render): slice r is rendered on group member r - member r on
+ * GPU r modulo the visible GPUs - the strips travel to the root GPU device to device (RCCL over xGMI between distinct GPUs, peer copies
+ * otherwise) and are merged there (sp_merge_replies, sp_place_strips); the merged image crosses the host link once.  The result has the
+ * same fields; `replies` then carry the slices' offsets and gauges only (their strips never existed in host memory) and `transport`
+ * names what moved the strips.  Groups are kept per worker count (renderSliced.closeGroups() releases them).
  * With `merge: false` the strips are not copied into one image (`data` is null; `replies` hold them): an image of 2^31 bytes or more -
  * BASELINE config 5 is exactly 2^31 - is beyond what one typed array can hold under Node 12, as it is beyond one canvas.
  * @param {{buffer: ArrayBuffer, format: string, n: number, width: number, workers?: number, window?: string|{window, weight},
@@ -33,6 +38,10 @@ function renderSliced(o, pool) {
     const gain = o.gain === undefined ? 6 : o.gain, range = o.range === undefined ? 30 : o.range
     const fmt = a.parseFormat(o.format)
     const width = o.width, sliceWidth = ~~(width / workers)             // spectroplot.js:1208
+    if (o.device) {
+        if (byName) throw new Error('renderSliced: device: true takes evaluated arrays (window, cmap), not names')
+        return renderOnGroup(a, o, { workers, n, w, block_norm, cmap, gain, range, fmt, width, sliceWidth })
+    }
     const own = !pool
     pool = pool || Array.from({ length: workers }, () => new HipWorker())
     const merged = o.merge === false ? null : new Uint8ClampedArray(4 * width * n)
@@ -83,6 +92,43 @@ function renderSliced(o, pool) {
         return { data: merged, width: o.waterfall ? n : width, height: o.waterfall ? width : n, c_hist, cB_hist, dBfs_min, dBfs_max,
             sliceWidth, replies }
     })
+}
+
+const groups = new Map()   // worker count -> {handle, queue}: a group renders one request at a time, like one worker
+
+function renderOnGroup(a, o, q) {
+    let entry = groups.get(q.workers)
+    if (!entry) {
+        const gpus = Math.max(1, a.deviceCount())
+        entry = { handle: a.createGroup(Array.from({ length: q.workers }, (_, i) => i % gpus)), queue: Promise.resolve() }
+        groups.set(q.workers, entry)
+    }
+    const g = entry.handle
+    const windowc = q.w.window instanceof Float64Array ? q.w.window : Float64Array.from(q.w.window)
+    const req = { format: q.fmt.id, buffer: o.buffer, n: q.n, windowc, block_norm: q.block_norm, gain: q.gain, range: q.range,
+        lut: packLut(q.cmap), width: q.width, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+    const run = () => new Promise((resolve, reject) => {
+        a.groupRender(g, req, (err, r) => {
+            if (err) { reject(err); return }
+            const gm = new Uint8ClampedArray(r.gauge_mins), gx = new Uint8ClampedArray(r.gauge_maxs), ga = new Uint8ClampedArray(r.gauge_amps)
+            const replies = []
+            for (let i = 0; i < q.workers; i++) {
+                const lo = i * q.sliceWidth, hi = lo + q.sliceWidth
+                replies.push({ offset: lo, gauge_mins: gm.subarray(lo, hi), gauge_maxs: gx.subarray(lo, hi), gauge_amps: ga.subarray(lo, hi), imageData: null })
+            }
+            resolve({ data: new Uint8ClampedArray(r.rgba), width: o.waterfall ? q.n : q.width, height: o.waterfall ? q.width : q.n,
+                c_hist: Array.from(r.c_hist), cB_hist: Array.from(r.cB_hist), dBfs_min: r.dBfs_min, dBfs_max: r.dBfs_max,
+                sliceWidth: q.sliceWidth, replies, transport: r.transport, members: r.members })
+        })
+    })
+    const p = entry.queue.then(run)
+    entry.queue = p.then(() => null, () => null)
+    return p
+}
+
+renderSliced.closeGroups = () => {
+    for (const e of groups.values()) native().destroyGroup(e.handle)
+    groups.clear()
 }
 
 /**

@@ -28,6 +28,13 @@
 //                                    does (lib/spectroplot.js:238-264, 1113-1146) and keeps the plan while they repeat
 //   namedResolve(window, cmap)                     -> {window, cmap, lutLength}: what the two option names resolve to (sp_named_resolve)
 //   planCreations(handle)                          -> how many plans this context has built (sp_context_plan_creations)
+//   createGroup(devices: number[])                 -> external handle of an sp_group: one member context per listed device
+//   destroyGroup(handle)                           -> like destroyContext
+//   groupRender(handle, req, cb) / groupRenderSync(handle, req)   req as for render, `width` = frames of the WHOLE image:
+//       sp_group_render - the caller's sliced render (lib/spectroplot.js:1206-1244) with the strips gathered device to device (RCCL or
+//       peer copies) and merged on the root; the reply is the merged result (rgba = the whole image, gauges [width]) plus
+//       {sliceWidth, members, transport: 'none' | 'rccl' | 'peer'}
+// One render at a time per handle: a second render on a handle whose first is still in flight throws (HipWorker serialises its own).
 #include <node_api.h>
 
 #include <cstdint>
@@ -88,6 +95,7 @@ bool get_bool(napi_env env, napi_value obj, const char *name)
 // context closed, and whoever brings the count to zero on a closed context destroys it.
 struct Ctx {
     sp_context *c = nullptr;
+    sp_group *g = nullptr;    // a group handle instead (createGroup): the renders go to sp_group_render
     int inflight = 0;
     bool closed = false;
     bool collected = false;   // the JS handle is gone: the struct itself may be deleted
@@ -98,6 +106,10 @@ void ctx_release(Ctx *x)
     if (x->closed && x->inflight == 0 && x->c) {
         sp_context_destroy(x->c);
         x->c = nullptr;
+    }
+    if (x->closed && x->inflight == 0 && x->g) {
+        sp_group_destroy(x->g);
+        x->g = nullptr;
     }
     if (x->collected && x->inflight == 0) delete x;
 }
@@ -207,6 +219,7 @@ void pool_free_cb(napi_env env, void *data, void *hint)
 struct Job {
     Ctx *owner = nullptr;
     sp_context *ctx = nullptr;
+    sp_group *group = nullptr;   // a group handle's job
     sp_request req{};
     std::vector<double> window;
     std::vector<uint8_t> lut;
@@ -250,11 +263,12 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j, bool
         return false;
     }
     j->owner = (Ctx *)p;
-    if (j->owner->closed || !j->owner->c) {
+    if (j->owner->closed || (!j->owner->c && !j->owner->g)) {
         napi_throw_error(env, nullptr, "context has been destroyed");
         return false;
     }
     j->ctx = j->owner->c;
+    j->group = j->owner->g;
     napi_value v;
     int32_t i32 = 0;
     j->named = named;
@@ -332,6 +346,11 @@ void run_job(Job *j)
     sp_reply r{};
     r.rgba = j->rgba; r.gauge_mins = j->gmin; r.gauge_maxs = j->gmax; r.gauge_amps = j->gamp;
     r.c_hist = j->c_hist.data(); r.cb_hist = j->cb_hist.data(); r.dbfs_minmax = j->minmax;
+    if (j->group) {
+        j->status = sp_group_render(j->group, &j->req, j->bytes, j->nbytes, j->width, &r);
+        if (j->status != SP_OK) j->error = sp_group_last_error(j->group);
+        return;
+    }
     if (j->named) {
         sp_named_request nr{};
         nr.format = j->nformat.c_str();
@@ -388,6 +407,12 @@ napi_value make_reply(napi_env env, Job *j)
     put_hist("cB_hist", j->cb_hist);
     napi_create_double(env, j->minmax[0], &v); napi_set_named_property(env, out, "dBfs_min", v);
     napi_create_double(env, j->minmax[1], &v); napi_set_named_property(env, out, "dBfs_max", v);
+    if (j->group) {
+        const int members = sp_group_size(j->group);
+        napi_create_int32(env, members, &v); napi_set_named_property(env, out, "members", v);
+        napi_create_int32(env, members > 0 ? j->width / members : 0, &v); napi_set_named_property(env, out, "sliceWidth", v);
+        napi_create_string_utf8(env, sp_group_transport(j->group), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "transport", v);
+    }
     return out;
 }
 
@@ -596,8 +621,40 @@ napi_value DestroyContext(napi_env env, napi_callback_info info)
     x->closed = true;
     ctx_release(x);
     napi_value v;
-    napi_get_boolean(env, x->c == nullptr, &v);    // true: released now; false: a render is still in flight, released when it ends
+    napi_get_boolean(env, x->c == nullptr && x->g == nullptr, &v);    // true: released now; false: a render is still in flight, released when it ends
     return v;
+}
+
+napi_value CreateGroup(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    uint32_t len = 0;
+    bool is_array = false;
+    if (argc < 1 || napi_is_array(env, argv[0], &is_array) != napi_ok || !is_array || napi_get_array_length(env, argv[0], &len) != napi_ok || len < 1) {
+        napi_throw_type_error(env, nullptr, "createGroup: a non-empty array of device indices expected");
+        return nullptr;
+    }
+    std::vector<int32_t> devices(len);
+    for (uint32_t i = 0; i < len; i++) {
+        napi_value e;
+        napi_get_element(env, argv[0], i, &e);
+        napi_get_value_int32(env, e, &devices[i]);
+    }
+    sp_group *g = nullptr;
+    const int rc = sp_group_create(devices.data(), (int32_t)len, &g);
+    if (rc) return throw_status(env, rc, rc == SP_ERR_NO_DEVICE ? "no HIP device: spectroplot-hip has no CPU fallback" : nullptr);
+    Ctx *x = new Ctx;
+    x->g = g;
+    napi_value ext;
+    if (napi_create_external(env, x, ctx_finalize, nullptr, &ext) != napi_ok) {
+        sp_group_destroy(g);
+        delete x;
+        napi_throw_error(env, nullptr, "napi_create_external failed");
+        return nullptr;
+    }
+    return ext;
 }
 
 void pinned_free_cb(napi_env env, void *data, void *hint)
@@ -761,6 +818,10 @@ napi_value Init(napi_env env, napi_value exports)
         {"renderNamedSync", nullptr, RenderNamedSync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"namedResolve", nullptr, NamedResolve, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"planCreations", nullptr, PlanCreations, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"createGroup", nullptr, CreateGroup, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"destroyGroup", nullptr, DestroyContext, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"groupRender", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"groupRenderSync", nullptr, RenderSync, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     napi_value v;

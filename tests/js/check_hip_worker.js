@@ -20,7 +20,7 @@ function ask(worker, message) {
 async function main() {
     const worker = new HipWorker()
     let failures = []
-    let checked = 0
+    let checked = 0, deviceMerged = 0
     for (const c of G.spec.worker_cases) {
         const e = G.expected.find(x => x.name === c.name)
         const pow2 = (c.n & (c.n - 1)) === 0
@@ -49,6 +49,21 @@ async function main() {
             if (JSON.stringify(m.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: merged c_hist`)
             if (!G.sameF64(m.dBfs_min, e.merged.dBfs_min) || !G.sameF64(m.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: merged range`)
             pool.forEach(w => w.terminate())
+            // the same sliced render as ONE native call with the merge on the device (sp_group_render through renderSliced's
+            // device: true): strips gathered device to device, merged on the root member, one image back
+            const d = await renderSliced({ buffer: G.makeInput(c), format: c.format, n: c.n, width: c.width, workers: c.slices, device: true,
+                window: { window: windowc, weight }, cmap: G.getCmap(c, false), gain: c.gain, range: c.range,
+                channelMode: !!c.channelMode, waterfall: !!c.waterfall })
+            if (G.sha256(d.data) !== e.merged.rgba_sha256) failures.push(`${c.name}: device-merged rgba`)
+            if (JSON.stringify(d.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: device-merged c_hist`)
+            if (JSON.stringify(d.cB_hist) !== JSON.stringify(m.cB_hist)) failures.push(`${c.name}: device-merged cB_hist`)
+            if (!G.sameF64(d.dBfs_min, e.merged.dBfs_min) || !G.sameF64(d.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: device-merged range`)
+            if (d.transport !== (c.slices === 1 ? 'none' : HipWorker.deviceCount() >= c.slices ? 'rccl' : 'peer')) failures.push(`${c.name}: transport ${d.transport}`)
+            d.replies.forEach((r, i) => {
+                for (const k of ['gauge_mins', 'gauge_maxs', 'gauge_amps'])
+                    if (Buffer.from(r[k]).toString('hex') !== e.slices[i][k]) failures.push(`${c.name}[${i}]: device-merged ${k}`)
+            })
+            deviceMerged++
         }
         checked++
     }
@@ -99,7 +114,9 @@ async function main() {
     }
 
     if (failures.length) { console.error(failures.slice(0, 30).join('\n')); console.error(`${failures.length} failures`); process.exit(1) }
-    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s)`)
+    renderSliced.closeGroups()
+    if (deviceMerged < 10) { console.error(`only ${deviceMerged} sliced cases went through the device merge`); process.exit(1) }
+    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s); ${deviceMerged} sliced cases also merged on the device (sp_group_render)`)
 }
 
 main().catch(e => { console.error(e); process.exit(1) })

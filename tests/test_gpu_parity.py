@@ -125,6 +125,41 @@ def test_golden_slices_through_worker_mirror(pkg, golden):
     w.terminate()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]], ids=lambda d: "%d_members" % len(d))
+def test_group_render_merges_on_the_device_like_the_callers_merge(pkg, golden, devices):
+    """sp_group_render: the caller's slice + merge (lib/spectroplot.js:1206-1244) from one process with the strips gathered device to
+    device and merged on the root member, against the merged vectors of the real reference for the same worker count.  One member needs
+    no transport; several members on this box's one GPU take the peer-copy path (RCCL's needs distinct devices)."""
+    g = pkg.Group(devices)
+    ran = 0
+    for c in golden.spec["worker_cases"]:
+        e = golden.expected[c["name"]]
+        if "merged" not in e or c["slices"] != len(devices):
+            continue
+        data = golden.input(c)
+        win, weight = pyoracle.window(c["window"], c["n"])
+        lut = golden.lut(c, force_ends=c["force_ends"])
+        m = g.render(c["format"], data, c["n"], win, 1.0 / weight, c["gain"], c["range"], lut, c["width"], c["channelMode"], c["waterfall"])
+        assert goldenlib.sha256(m["rgba"]) == e["merged"]["rgba_sha256"], c["name"]
+        assert [int(v) for v in m["c_hist"]] == e["merged"]["c_hist"], c["name"]
+        assert goldenlib.same_f64(m["dBfs_min"], e["merged"]["dBfs_min"]) and goldenlib.same_f64(m["dBfs_max"], e["merged"]["dBfs_max"]), c["name"]
+        sw = m["slice_width"]
+        assert sw == e["merged"]["slice_width"]
+        cb = np.zeros(1000, dtype=np.int64)
+        for i, es in enumerate(e["slices"]):
+            for k in ("gauge_mins", "gauge_maxs", "gauge_amps"):
+                assert bytes(m[k][i * sw:(i + 1) * sw]).hex() == es[k], (c["name"], i, k)
+            for b, v in es["cB_hist"].items():
+                cb[int(b)] += v
+        assert np.array_equal(m["cB_hist"].astype(np.int64), cb), c["name"]
+        for k in ("gauge_mins", "gauge_maxs", "gauge_amps"):
+            assert not m[k][len(devices) * sw:].any(), (c["name"], k)
+        assert g.transport() == ("none" if len(devices) == 1 else "peer")
+        ran += 1
+    g.close()
+    assert ran >= 1, "no golden case with %d slices" % len(devices)
+
+
 SEEDED = [
     # fmt, log2 samples, n, width, window, gain, range, channelMode, waterfall
     ("CF32", 18, 1024, 256, "blackmanHarris", 6, 30, False, False),
