@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the I/Q STFT -> RGBA hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3|cfg4|cfg5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3|cfg4|cfg5] [--no-cpu-baseline] [--rotate K]
 
-A "step" is one pass of the hot path (sp_plan_execute: frame-loop kernel + the two finish kernels) over one capture of
-synthetic I/Q that is already resident in HBM, producing the RGBA image, both histograms, the gauges and the dBfs range
+A "step" is one pass of the hot path (sp_plan_execute: ONE kernel, the frame loop, which also produces the side outputs) over one
+capture of synthetic I/Q that is already resident in HBM, producing the RGBA image, both histograms, the gauges and the dBfs range
 in HBM.  Default workload = BASELINE.json configs[1]: 16 MSample (2^24) cf32, n = 1024, Blackman-Harris, viridis,
 gain 6, range 30, spectrogram layout, W = S/n = 16384 frames.  With N > 1 (launched by torch.distributed.run, one rank
 per GPU) every rank renders its own contiguous time slice of an N-times longer capture (weak scaling, the reference's
-own slice scheme, lib/spectroplot.js:1206-1228) and the per-slice histograms / dBfs range are combined with RCCL
-all-reduces inside the timed region; the RGBA strips stay resident on their GPUs (see DESIGN.md "Multi-GPU") and the
+own slice scheme, lib/spectroplot.js:1206-1228) and the per-slice histograms / dBfs range are combined on the device
+(an RCCL all-gather of the records per batch of renders + sp_merge_replies) inside the timed region; the RGBA strips stay resident on their GPUs (see DESIGN.md "Multi-GPU") and the
 gather of the strips to rank 0 is timed separately and reported as extra fields.
 
 Prints ONE JSON line on rank 0.
@@ -97,12 +97,15 @@ def e2e_dropin():
         return {"workload": "one config-2 worker message (16 MSample cf32 in, 64 MiB RGBA out) through HipWorker under Node",
                 "ms_per_message": a["ms_per_message"], "msamples_per_s": a["msamples_per_s"], "first_message_ms": a.get("first_message_ms"),
                 "ms_per_message_pinned_request": b["ms_per_message"], "msamples_per_s_pinned_request": b["msamples_per_s"],
-                "config1_ms_per_message": pick["config 1"]["ms_per_message"], "config1_js_worker_ms": pick["config 1"]["js_worker_ms"]}
+                "config1_ms_per_message": pick["config 1"]["ms_per_message"], "config1_js_worker_ms": pick["config 1"]["js_worker_ms"],
+                # the longer direction of a config-2 message (128 MiB in, 64 MiB out, full duplex) against the host link's 63 GB/s
+                "pcie_frac": (128 * 2**20) / (b["ms_per_message"] * 1e-3) / 63e9,
+                "pcie_frac_note": "134 MB of samples per message / ms_per_message_pinned_request / 63 GB/s (PCIe Gen5 x16, one direction)"}
     except Exception as e:
         return {"failed": repr(e)}
 
 
-PROFILE_TAG = "r03"   # profiles/<tag>_<config>_{traffic,valu}.json: committed rocprofv3 --pmc summaries of this same command
+PROFILE_TAGS = ("r04", "r03")   # profiles/<tag>_<config>_{traffic,valu}.json: committed rocprofv3 --pmc summaries of this same command (newest first)
 
 
 def rocprof_kernel_us(argv_config):
@@ -119,8 +122,16 @@ def rocprof_kernel_us(argv_config):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "400", "--warmup", "100", "--no-cpu-baseline", "--no-e2e", "--no-rocprof"] + argv_config
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+               "--steps", "400", "--warmup", "100", "--no-cpu-baseline", "--no-e2e", "--no-rocprof", "--no-extras"] + argv_config
+        # (its own process group: on a timeout the profiler AND the python below it go, nothing keeps the GPU busy behind our back)
+        child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            child.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(child.pid, signal.SIGKILL)
+            child.wait()
+            return None
         best = None
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
@@ -139,8 +150,12 @@ def valu_roofline(config, kernel_us, frames):
     """The resource that binds the frame loop in fact: VALU issue.  Counted wave-instructions per launch (rocprofv3
     --pmc, committed under profiles/) times the measured issue cost of their class with two waves per SIMD (profiles/r02_op_cost.txt),
     over the chip's 1024 SIMDs at 2.4 GHz: the time the launch would take if no SIMD ever waited."""
-    f = os.path.join(ROOT, "profiles", "%s_%s_valu.json" % (PROFILE_TAG, config))
-    if not os.path.exists(f):
+    f, tag = None, None
+    for tag in PROFILE_TAGS:
+        f = os.path.join(ROOT, "profiles", "%s_%s_valu.json" % (tag, config))
+        if os.path.exists(f):
+            break
+    else:
         return None
     c = json.load(open(f))["counters"]
     if not c.get("SQ_INSTS_VALU"):
@@ -157,7 +172,7 @@ def valu_roofline(config, kernel_us, frames):
             "valu_wave_insts": g("SQ_INSTS_VALU"), "cycles_per_inst": cost["f64"], "class_costs": cost,
             "class_counts": {"f64": f64, "cvt": cvt, "trans_f32": trans, "int": i32, "f32": f32, "other": other},
             "floor_us": floor_us, "kernel_us": kernel_us, "frac": floor_us / kernel_us if kernel_us else None,
-            "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r02_op_cost.txt" % (PROFILE_TAG, config)}
+            "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r02_op_cost.txt" % (tag, config)}
 
 
 def launch_ranks(argv, gpus):
@@ -192,6 +207,10 @@ def main():
     ap.add_argument("--merge-every", type=int, default=16,
                     help="N > 1: the side-output records of this many renders travel in ONE all-gather (1 = one collective per render)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "frames"], help="A/B runs: force a device kernel")
+    ap.add_argument("--rotate", type=int, default=3,
+                    help="N = 1: also time the kernel over this many capture / image sets in rotation, a working set beyond the 256 MiB "
+                         "Infinity Cache (reported as roofline.rotating; 0 or 1 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rotating-buffers and two-requests-in-flight legs (N = 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -200,12 +219,15 @@ def main():
     # dominant kernel's duration as rocprofv3 reports it: a short child run of this command, before this process touches the GPU
     prof = None
     if args.gpus == 1 and not args.no_rocprof and "WORLD_SIZE" not in os.environ:
-        prof = rocprof_kernel_us(["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else []))
+        prof = rocprof_kernel_us(["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else [])
+                                 + (["--no-rgba"] if args.no_rgba else []))
 
     import numpy as np
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
+    import importlib
+    sharding = importlib.import_module("spectroplot_js_amd.sharding")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -262,55 +284,29 @@ def main():
     L = len(lut)
     P = L + 1000 + 2
     M = max(1, args.merge_every) if dist is not None else 1
-    records = [torch.zeros(M * P, dtype=torch.int64, device=dev) for _ in range(2)]
-    gathered = [torch.zeros(world * M * P, dtype=torch.int64, device=dev) for _ in range(2)] if dist is not None else None
-    merged_buf = torch.zeros(P, dtype=torch.int64, device=dev)
-    state = {"k": 0, "pending": None, "last": None}
+
+    def merge_on_device(by_rank, count, out):
+        # the caller's merge of the slices' side outputs (lib/spectroplot.js:1229-1238), on device: one render's records, every rank's
+        p = out.data_ptr()
+        ctx.merge_replies(by_rank.data_ptr(), count, L, p, p + 8 * L, p + 8 * (L + 1000))
+
+    # (spectroplot-js_amd/sharding.py RecordBatcher: the batching, the all-gather per batch and the merge one batch later; its shapes
+    # and views are exercised on CPU tensors with gloo by tests/test_sharding_gloo.py)
+    batcher = sharding.RecordBatcher(world, M, P, dev, merge_fn=merge_on_device, collectives=dist is not None)
+    records = batcher.records
+    merged_buf = batcher.merged
 
     def run_slice(rec, j=0):
         p = rec.data_ptr() + 8 * P * j
         plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
                      p, p + 8 * L, p + 8 * (L + 1000))
 
-    def merge(slot, count):
-        # the caller's merge of the slices' side outputs (lib/spectroplot.js:1229-1238), on device: render by render, every
-        # rank's record of that render side by side
-        by_render = gathered[slot].view(world, M, P).transpose(0, 1).contiguous() if M > 1 else gathered[slot]
-        p = merged_buf.data_ptr()
-        for j in range(count):
-            ctx.merge_replies(by_render.data_ptr() + 8 * world * P * j, world, L, p, p + 8 * L, p + 8 * (L + 1000))
-
-    def ship(slot, count):
-        # every rank gathers all ranks' records of the batch (10 KB per render and rank); queued behind the batch's kernels, it
-        # runs while the next batch computes.  The previous batch's gather has long finished: merge it.
-        work = dist.all_gather_into_tensor(gathered[slot], records[slot], async_op=True)
-        if state["pending"] is not None:
-            pw, pslot, pcount = state["pending"]
-            pw.wait()
-            merge(pslot, pcount)
-        state["pending"] = (work, slot, count)
-
     def step():
-        k = state["k"]
-        state["k"] += 1
-        slot, j = (k // M) & 1, k % M
-        run_slice(records[slot], j)
-        state["last"] = (slot, j)
-        if dist is not None and j == M - 1:
-            ship(slot, M)
+        run_slice(batcher.next_record())
+        batcher.rendered()
 
     def finish_pending():
-        if dist is None:
-            return
-        k = state["k"]
-        if k % M:                                             # a partial batch at the end of a run
-            ship((k // M) & 1, k % M)
-            state["k"] = (k // M + 1) * M
-        if state["pending"] is not None:
-            pw, pslot, pcount = state["pending"]
-            pw.wait()
-            merge(pslot, pcount)
-            state["pending"] = None
+        batcher.finish()
 
     def sync():
         if dist is not None:
@@ -349,7 +345,7 @@ def main():
     finish_pending()                                          # the last render's merge belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
-    final = merged_buf if dist is not None else records[state["last"][0]][P * state["last"][1]:]
+    final = batcher.final_record()
     hsum = int(final[:L].sum().item())                        # all slices after the merge
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -374,16 +370,102 @@ def main():
     # time as measured, un-corrected (it contains the dispatch latency: a lower bound on the fraction)
     kernel_ms = prof["avg_us"] * 1e-3 if prof else kernel_ms_events
 
+    rotating = two_in_flight = None
+    if world == 1 and dist is None and not args.no_extras:
+        # (a) Is the default figure HBM bandwidth?  Config 2's working set (128 MiB in + 64 MiB out) fits the 256 MiB Infinity Cache and
+        # every step re-renders the same buffers.  The same kernel over K capture / image sets in rotation touches K times that.
+        K = args.rotate
+        if K >= 2:
+            try:
+                ins = [d_in] + [torch.empty_like(d_in) for _ in range(K - 1)]
+                outs = [rgba] + [torch.empty_like(rgba) for _ in range(K - 1)]
+                for k in range(1, K):
+                    ctx.synth_trinoise(ins[k].data_ptr(), fmt, k * S, S, GEN["seed"], GEN["step"], GEN["gshift"], GEN["amp"], GEN["namp"])
+                rec = records[0]
+
+                def run_set(k):
+                    plan.execute(ins[k].data_ptr(), S * sw, W, 0 if args.no_rgba else outs[k].data_ptr(), gauges.data_ptr(), gauges.data_ptr() + W,
+                                 gauges.data_ptr() + 2 * W, rec.data_ptr(), rec.data_ptr() + 8 * L, rec.data_ptr() + 8 * (L + 1000))
+                nrot = max(40, min(args.steps, 400))
+                for i in range(2 * K):
+                    run_set(i % K)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(nrot):
+                    run_set(i % K)
+                torch.cuda.synchronize()
+                ms_rot = (time.perf_counter() - t0) * 1e3 / nrot
+                t0 = time.perf_counter()
+                for i in range(nrot):
+                    run_set(0)
+                torch.cuda.synchronize()
+                ms_one = (time.perf_counter() - t0) * 1e3 / nrot
+                ctx.enable_timing(True)
+                ev = []
+                for i in range(40):
+                    for j in range(4):
+                        run_set((4 * i + j) % K)
+                    torch.cuda.synchronize()
+                    ev.append(ctx.last_kernel_ms())
+                ctx.enable_timing(False)
+                ev_rot = float(np.mean(ev))
+                ratio = ev_rot / kernel_ms_events
+                rotating = {"sets": K, "working_set_MiB": K * (S * sw + rgba.numel()) / 2**20, "ms_per_step_rotating": ms_rot,
+                            "ms_per_step_one_set_same_loop": ms_one, "kernel_ms_event_pair_rotating": ev_rot,
+                            "kernel_ms_event_pair_one_set": kernel_ms_events, "ratio": ratio,
+                            "kernel_ms_rotating": kernel_ms * ratio,
+                            "verdict": ("within 2 %: the default figure does not lean on the Infinity Cache" if abs(ratio - 1) <= 0.02 else
+                                        "differs by more than 2 %: the default figure is Infinity-Cache bandwidth, not HBM bandwidth")}
+                del ins, outs
+            except RuntimeError as e:          # (out of device memory on a small card: reported, not fatal)
+                rotating = {"failed": repr(e)}
+        # (b) Two requests in flight on one GPU, as the reference's pool keeps several workers busy: two contexts on two streams, each
+        # with its own plan and outputs.  A launch's workgroups occupy whole CUs, so the two do not share CUs, but the tail of one launch
+        # (CUs that have finished) overlaps the start of the next.  An extra figure, never the headline.
+        try:
+            ctx2 = pkg.Context(local_rank)
+            plan2 = ctx2.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, waterfall=args.waterfall)
+            if args.kernel != "auto":
+                plan2.force_kernel(args.kernel)
+            rgba2 = torch.empty_like(rgba)
+            gauges2 = torch.empty_like(gauges)
+            rec2 = torch.zeros(P, dtype=torch.int64, device=dev)
+            ctx.set_stream(0)                      # each context on its own (non-blocking) stream
+
+            def both():
+                plan.execute(d_in.data_ptr(), S * sw, W, rgba_ptr, gauges.data_ptr(), gauges.data_ptr() + W, gauges.data_ptr() + 2 * W,
+                             records[0].data_ptr(), records[0].data_ptr() + 8 * L, records[0].data_ptr() + 8 * (L + 1000))
+                plan2.execute(d_in.data_ptr(), S * sw, W, 0 if args.no_rgba else rgba2.data_ptr(), gauges2.data_ptr(), gauges2.data_ptr() + W,
+                              gauges2.data_ptr() + 2 * W, rec2.data_ptr(), rec2.data_ptr() + 8 * L, rec2.data_ptr() + 8 * (L + 1000))
+            npair = max(20, min(args.steps, 400) // 2)
+            for _ in range(10):
+                both()
+            ctx.synchronize()
+            ctx2.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(npair):
+                both()
+            ctx.synchronize()
+            ctx2.synchronize()
+            dt2 = time.perf_counter() - t0
+            ok2 = bool(torch.equal(rec2[:L], records[0][:L])) and (args.no_rgba or bool(torch.equal(rgba2, rgba)))
+            two_in_flight = {"value_two_in_flight": 2 * npair * W / dt2, "unit": "frames/s", "ms_per_request": dt2 / (2 * npair) * 1e3,
+                             "requests": 2 * npair, "outputs_equal": ok2,
+                             "note": "two contexts / streams / plans on one GPU rendering the same capture into separate outputs, back to back"}
+            plan2.close()
+            ctx2.close()
+            ctx.set_stream(stream.cuda_stream)
+        except Exception as e:
+            two_in_flight = {"failed": repr(e)}
+
     gather_ms = place_ms = merged_ok = None
     if dist is not None and not args.no_gather:
         # the caller's putImageData of every slice (lib/spectroplot.js:1241-1244), HBM to HBM: the strips are gathered into ONE device
         # buffer on rank 0 (rank order) and placed in the merged image by sp_place_strips; both steps are timed, outside the timed region
         per = rgba.numel()
-        allstrips = torch.empty(world * per, dtype=torch.uint8, device=dev) if rank == 0 else None
-        bufs = [allstrips[r * per:(r + 1) * per] for r in range(world)] if rank == 0 else None
         sync()
         g0 = time.perf_counter()
-        dist.gather(rgba, bufs, dst=0)
+        allstrips = sharding.gather_to_one_buffer(rgba, dst=0)
         sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
@@ -410,6 +492,19 @@ def main():
             merged_ok = bool(torch.equal(image, want))
             del want, one, tmp_in, image, allstrips
 
+    ranks_seen = None
+    if dist is not None:
+        # who took part: rank, device index and PCI bus id per rank, so that a scaling run shows N distinct GPUs
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "name": props.name,
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
+                                                  getattr(props, "pci_device_id", -1) & 0xff),
+                "uuid": str(getattr(props, "uuid", ""))}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": args.backend, "ranks": seen,
+                      "distinct_devices": len({(r["pci_bus_id"], r["uuid"]) for r in seen})}
+
     stride_eff = min((S - n) / (W - 1), n)
     bytes_per_frame = sw * stride_eff + 4 * n + 3                 # unique input bytes + RGBA + 3 gauge bytes
     algo_bytes = bytes_per_frame * W
@@ -417,7 +512,7 @@ def main():
     frames_per_s = world * W * args.steps / dt
 
     traffic, traffic_source = None, None
-    for tag in (PROFILE_TAG, "r02"):
+    for tag in PROFILE_TAGS + ("r02",):
         tfile = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (tag, args.config))
         if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed, not live)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
@@ -448,10 +543,13 @@ def main():
                          "kernel_ms_event_pair": kernel_ms_events, "event_pair_overhead_ms": event_overhead_ms,
                          "kernel_ms_event_pair_minus_overhead": max(kernel_ms_events - event_overhead_ms, 0.0),
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame,
-                         "frac_of_copy_ceiling_6290": achieved / 6290.0},
+                         "frac_of_copy_ceiling_6290": achieved / 6290.0, "rotating": rotating},
             "roofline_valu": valu_roofline(args.config, kernel_ms * 1e3, W) if world == 1 else None,
+            "value_two_in_flight": two_in_flight.get("value_two_in_flight") if two_in_flight else None,
+            "two_in_flight": two_in_flight,
             "checks": {"c_hist_sum": hsum, "expected": world * W * n},
             "renders_per_collective": M if dist is not None else None,
+            "rccl_ranks_seen": ranks_seen,
         }
         if gather_ms is not None:
             out["rgba_gather_ms"] = gather_ms

@@ -64,6 +64,90 @@ def gather_strips(strip, n, width, waterfall, dst=0, group=None):
     return img.reshape(-1)
 
 
+def gather_to_one_buffer(strip, dst=0, group=None):
+    """Gathers every rank's strip (1-D uint8 tensor, the same length on all ranks) into ONE buffer on `dst`, rank order - the layout
+    sp_place_strips takes: the receive list handed to dist.gather is a list of views of that buffer.  Returns it on `dst`, None
+    elsewhere."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    per = strip.numel()
+    allstrips, bufs = None, None
+    if rank == dst:
+        allstrips = torch.empty(max(world * per, 16), dtype=torch.uint8, device=strip.device)
+        bufs = [allstrips[r * per:(r + 1) * per] for r in range(world)]
+    dist.gather(strip, bufs, dst=dst, group=group)
+    return allstrips
+
+
+class RecordBatcher:
+    """The side-output records of a stream of sliced renders, merged M renders per collective (what bench.py --gpus N times).
+
+    Every render of this rank writes one record [c_hist | cB_hist | dBfs_min, dBfs_max] of `record_len` int64 into the batch buffer
+    (`next_record()` names the place); after M renders ONE all_gather_into_tensor ships the batch (queued behind the batch's kernels,
+    it runs while the next batch computes: two buffers in rotation) and the batch gathered before it is reduced render by render with
+    `merge_fn(by_rank, count, out)` - `by_rank` the `count` ranks' records of one render end to end, `out` the merged record
+    (sp_merge_replies on the device; the caller's merge, lib/spectroplot.js:1229-1238).  With `collectives=False` (one rank, no process
+    group) the records are only kept."""
+
+    def __init__(self, world, renders_per_collective, record_len, device, merge_fn=None, group=None, collectives=True):
+        self.world, self.M, self.P = int(world), max(1, int(renders_per_collective)), int(record_len)
+        self.group, self.merge_fn, self.collectives = group, merge_fn, bool(collectives)
+        self.records = [torch.zeros(self.M * self.P, dtype=torch.int64, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(self.world * self.M * self.P, dtype=torch.int64, device=device) for _ in range(2)] if collectives else None
+        self.merged = torch.zeros(self.P, dtype=torch.int64, device=device)
+        self.k, self.pending, self.last = 0, None, None
+
+    def next_record(self):
+        """The int64 view [record_len] the next render writes its record into."""
+        slot, j = (self.k // self.M) & 1, self.k % self.M
+        return self.records[slot][j * self.P:(j + 1) * self.P]
+
+    def by_render(self, slot):
+        """The gathered batch [rank][render][record] re-ordered to [render][rank][record]: one render's records end to end."""
+        g = self.gathered[slot]
+        return g.view(self.world, self.M, self.P).transpose(0, 1).contiguous() if self.M > 1 else g.view(1, self.world, self.P)
+
+    def _merge(self, slot, count):
+        b = self.by_render(slot)
+        for j in range(count):
+            self.merge_fn(b[j].reshape(-1), self.world, self.merged)
+
+    def _ship(self, slot, count):
+        work = dist.all_gather_into_tensor(self.gathered[slot], self.records[slot], group=self.group, async_op=True)
+        if self.pending is not None:          # the previous batch's gather has long finished: merge it
+            pw, pslot, pcount = self.pending
+            pw.wait()
+            self._merge(pslot, pcount)
+        self.pending = (work, slot, count)
+
+    def rendered(self):
+        """The render that writes next_record() has been queued."""
+        slot, j = (self.k // self.M) & 1, self.k % self.M
+        self.last = (slot, j)
+        self.k += 1
+        if self.collectives and j == self.M - 1:
+            self._ship(slot, self.M)
+
+    def finish(self):
+        """Ships a partial batch and merges what is still in flight (every rank calls it at the same point)."""
+        if not self.collectives:
+            return
+        if self.k % self.M:
+            self._ship((self.k // self.M) & 1, self.k % self.M)
+            self.k = (self.k // self.M + 1) * self.M
+        if self.pending is not None:
+            pw, pslot, pcount = self.pending
+            pw.wait()
+            self._merge(pslot, pcount)
+            self.pending = None
+
+    def final_record(self):
+        """The merged record of the last render (after finish()), or this rank's own last record without collectives."""
+        if self.collectives:
+            return self.merged
+        slot, j = self.last
+        return self.records[slot][j * self.P:(j + 1) * self.P]
+
+
 def render_sharded(render_fn, data, fmt, n, width, windowc, weight, cmap, gain, rng, channel_mode=False, waterfall=False,
                    force_ends=True, device=None, dst=0, group=None):
     """One capture over all ranks of the process group.  `render_fn(message) -> reply` is this rank's worker
@@ -114,9 +198,17 @@ def render_sharded_device(plan, d_slice, width, waterfall=False, dst=0, group=No
     if stream.cuda_stream == 0:
         stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))   # whatever produced d_slice there
+    # The context's work so far (its own stream, or one a caller bound) must not overlap what follows: its workspaces rely on one
+    # stream's order.  The binding is restored on the way out.
+    previous = ctx.get_stream()
+    if previous != stream.cuda_stream:
+        ctx.synchronize()
     ctx.set_stream(stream.cuda_stream)
-    with torch.cuda.stream(stream):
-        return _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, group, want_image, rank, world, slw, P)
+    try:
+        with torch.cuda.stream(stream):
+            return _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, group, want_image, rank, world, slw, P)
+    finally:
+        ctx.set_stream(previous)
 
 
 def _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, group, want_image, rank, world, slw, P):
@@ -137,11 +229,7 @@ def _render_sharded_device_on(stream, plan, d_slice, width, waterfall, dst, grou
     image = None
     if want_image:
         per = 4 * slw * n
-        bufs = None
-        if rank == dst:
-            allstrips = torch.empty(max(world * per, 16), dtype=torch.uint8, device=dev)
-            bufs = [allstrips[r * per:(r + 1) * per] for r in range(world)]          # views: the gather fills one buffer, rank order
-        dist.gather(strip[:per], bufs, dst=dst, group=group)
+        allstrips = gather_to_one_buffer(strip[:per], dst=dst, group=group)          # one buffer on dst, rank order
         if rank == dst:
             image = torch.zeros(4 * width * n, dtype=torch.uint8, device=dev)        # un-rendered columns stay blank, as on the canvas
             if per:

@@ -167,3 +167,89 @@ def test_device_resident_sharded_render_reproduces_reference_merge(tmp_path, gol
     mp.spawn(_device_rank_main, args=(world, _free_port(), names, str(tmp_path), backend), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("rank%d" % r)).read() == "ok", r
+
+
+def _batcher_rank(rank, world, port, steps, per, out_dir):
+    """bench.py's N > 1 bookkeeping on CPU tensors: sharding.RecordBatcher (batched all-gather of the records, merge one batch later)
+    and sharding.gather_to_one_buffer (the strips into views of one buffer), with the device library replaced by torch arithmetic."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    load_package()
+    from spectroplot_js_amd import sharding
+    L, CB = 7, 1000
+    P = L + CB + 2
+    f64 = lambda t: t.view(torch.float64)  # noqa: E731
+
+    def record_of(r, k):        # what rank r's render k "produces": counts that name (rank, render), a dBfs range as f64 bit patterns
+        rec = torch.zeros(P, dtype=torch.int64)
+        rec[:L] = torch.arange(L) + 100 * r + k
+        rec[L:L + CB] = (torch.arange(CB) * (r + 1) + k) % 13
+        f64(rec[L + CB:])[:] = torch.tensor([-1.5 * r - k, -150.0 + r + 2.0 * k], dtype=torch.float64)
+        return rec
+
+    merges = []
+
+    def merge_fn(by_rank, count, out):      # sp_merge_replies in torch: sums, min / max from (0, -200)  (lib/spectroplot.js:1229-1238)
+        assert by_rank.shape == (count * P,) and count == world and by_rank.is_contiguous()
+        recs = by_rank.view(count, P)
+        out[:L + CB] = recs[:, :L + CB].sum(0)
+        mm = f64(recs[:, L + CB:].contiguous()).view(count, 2)
+        f64(out[L + CB:])[:] = torch.stack([torch.minimum(mm[:, 0].min(), torch.tensor(0.0, dtype=torch.float64)),
+                                            torch.maximum(mm[:, 1].max(), torch.tensor(-200.0, dtype=torch.float64))])
+        merges.append(out.clone())
+
+    ok = True
+    for M in (1, 3, 16):
+        merges.clear()
+        b = sharding.RecordBatcher(world, M, P, "cpu", merge_fn=merge_fn)
+        ok &= b.records[0].shape == (M * P,) and b.gathered[0].shape == (world * M * P,)
+        for k in range(steps):
+            rec = b.next_record()
+            ok &= rec.shape == (P,)
+            rec.copy_(record_of(rank, k))
+            b.rendered()
+        b.finish()
+        ok &= len(merges) == steps                      # every render merged once, in order, batches that do not divide the steps included
+        for k, got in enumerate(merges):
+            want = torch.zeros(P, dtype=torch.int64)
+            merge_fn_expected = sum(record_of(r, k)[:L + CB] for r in range(world))
+            want[:L + CB] = merge_fn_expected
+            f64(want[L + CB:])[:] = torch.tensor([min(0.0, min(-1.5 * r - k for r in range(world))),
+                                                 max(-200.0, max(-150.0 + r + 2.0 * k for r in range(world)))], dtype=torch.float64)
+            ok &= bool(torch.equal(got, want))
+        ok &= bool(torch.equal(b.final_record(), merges[-1]))
+    # one rank without a process group keeps its own records
+    solo = sharding.RecordBatcher(1, 1, P, "cpu", collectives=False)
+    solo.next_record().copy_(record_of(rank, 5))
+    solo.rendered()
+    solo.finish()
+    ok &= bool(torch.equal(solo.final_record(), record_of(rank, 5)))
+    # strips: one buffer on the root, rank order
+    strip = (torch.arange(per, dtype=torch.int64) * (rank + 3) % 251).to(torch.uint8)
+    allstrips = sharding.gather_to_one_buffer(strip, dst=0)
+    if rank == 0:
+        ok &= allstrips.shape == (max(world * per, 16),)
+        for r in range(world):
+            ok &= bool(torch.equal(allstrips[r * per:(r + 1) * per], (torch.arange(per, dtype=torch.int64) * (r + 3) % 251).to(torch.uint8)))
+    else:
+        ok &= allstrips is None
+    with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+        f.write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_record_batches_and_strip_gather_of_the_bench_on_cpu(tmp_path, world):
+    """The bookkeeping bench.py --gpus N runs around its renders - records in batches of M per collective (M = 1, 3, 16 against 20
+    renders: partial batches, two buffers in rotation), each render's records merged exactly once and in order; strips gathered into
+    views of one buffer - with gloo on CPU tensors, so that a first multi-GPU run is not its first run."""
+    port = _free_port()
+    mp.spawn(_batcher_rank, args=(world, port, 20, 4 * 6 * 8, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"

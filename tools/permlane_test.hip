@@ -1,4 +1,4 @@
-// Prints what v_permlane16_swap / v_permlane32_swap do on gfx950 (used by the register transpose in sp_kernel_lds.h).
+// Prints what v_permlane16_swap / v_permlane32_swap do on gfx950 (used by the register transpose in sp_frame_parts.h, exchange_permlane).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned *y)
