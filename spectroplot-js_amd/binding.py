@@ -85,7 +85,6 @@ class Library:
         L.sp_context_destroy.argtypes = [vp]
         L.sp_context_destroy.restype = None
         L.sp_context_set_stream.argtypes = [vp, vp]
-        L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.sp_context_synchronize.argtypes = [vp]
         L.sp_render.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply)]
         L.sp_render_named.argtypes = [vp, C.POINTER(_NamedRequest), vp, sz, i32, C.POINTER(_Reply)]
@@ -109,6 +108,8 @@ class Library:
         L.sp_merge_replies.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_place_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
+        if not hasattr(L, "sp_group_create"):
+            return          # (an older build loaded as an experiment variant, tools/ab_variants.sh: everything above is all it has)
         L.sp_group_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
         L.sp_group_destroy.argtypes = [vp]
         L.sp_group_destroy.restype = None
@@ -118,6 +119,7 @@ class Library:
         L.sp_group_transport.argtypes = [vp]
         L.sp_group_last_error.restype = C.c_char_p
         L.sp_group_last_error.argtypes = [vp]
+        L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
 
     @classmethod
     def get(cls):
