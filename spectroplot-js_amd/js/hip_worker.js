@@ -104,13 +104,9 @@ class HipWorker {
         return new Promise((resolve, reject) => {
             let req
             try { req = this._request(m) } catch (e) { reject(e); return }
-            // Small requests are rendered on the calling thread: the hand-off to a libuv thread and back costs more (~0.25 ms) than the
-            // render itself (a 1-MSample request: 0.15 ms through the C ABI), and the event loop is held for no longer than that.
-            // The reply still arrives asynchronously and in order (this runs inside the instance's promise queue).
-            if (req.buffer.byteLength + 4 * req.width * req.n <= HipWorker.syncRenderLimit) {
-                try { resolve(this._wrap(m, addon().renderSync(this._ctx, req))) } catch (e) { reject(e) }
-                return
-            }
+            // (Always on a libuv thread.  Rendering small requests on the calling thread was tried - the hand-off costs 0.06-0.08 ms of a
+            // 0.36 ms config-1 message - and is slower: a chain of replies that resolves in microtasks never lets V8 run the finalisers
+            // that return reply images to the pool, so every reply takes a fresh, unpinned block: 0.51 ms, tools/js_config1_message.js.)
             addon().render(this._ctx, req, (err, r) => err ? reject(err) : resolve(this._wrap(m, r)))
         })
     }
@@ -166,12 +162,6 @@ class HipWorker {
     }
 }
 
-/**
- * Requests whose sample buffer plus image stay below this many bytes are rendered synchronously inside postMessage's queue (0 = every
- * request goes to a libuv thread).  8 MiB: a config-1 message (2 MiB in, 4 MiB out) qualifies, anything that takes the GPU or the host
- * link a millisecond does not.
- */
-HipWorker.syncRenderLimit = 8 << 20
 /** A constructor bound to one device, for `workerOrUrl: HipWorker.onDevice(3)`. */
 HipWorker.onDevice = (device) => class extends HipWorker { constructor() { super({ device }) } }
 HipWorker.deviceCount = () => addon().deviceCount()

@@ -48,10 +48,11 @@ PY
   cp $OUT/${TAG}_${C}_valu.json $ROOT/profiles/${TAG}_${C}_valu.json
   # 2. kernel durations
   rm -rf /tmp/kt_$C
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$C -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-rocprof --config $C > /tmp/kt_$C.log 2>&1
-  cp $(find /tmp/kt_$C -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${C}_kernel_stats.csv
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$C -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-rocprof --no-extras --config $C < /dev/null > /tmp/kt_$C.log 2>&1
+  KS=$(find /tmp/kt_$C -name "*kernel_stats.csv" 2>/dev/null | head -1)
+  [ -n "$KS" ] && cp "$KS" $OUT/${TAG}_${C}_kernel_stats.csv
   # 3. the bench line (un-profiled); the CPU baseline and the Node drop-in leg ride with the headline config
-  if [ "$C" = "cfg2" ]; then timeout 900 python3 $ROOT/bench.py --config $C > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err
-  else timeout 900 python3 $ROOT/bench.py --config $C --no-e2e > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err; fi
+  if [ "$C" = "cfg2" ]; then timeout 900 python3 $ROOT/bench.py --config $C < /dev/null > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err
+  else timeout 900 python3 $ROOT/bench.py --config $C --no-e2e < /dev/null > $OUT/${TAG}_${C}_bench.json 2> /tmp/bench_$C.err; fi
   tail -c 600 $OUT/${TAG}_${C}_bench.json; echo
 done

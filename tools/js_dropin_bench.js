@@ -45,7 +45,17 @@ async function main() {
         const t_cold = process.hrtime.bigint()
         await ask(worker, m)
         const cold_ms = Number(process.hrtime.bigint() - t_cold) / 1e6
-        for (let i = 0; i < 11; i++) await ask(worker, m)
+        // ... until the pool is steady: no fresh block for 24 messages in a row (small replies weigh little in V8's books, so it collects
+        // them rarely and the pool needs a few dozen blocks before every reply finds a recycled one), at most 400 messages
+        const addon = require(path.join(root, 'spectroplot-js_amd', 'lib', 'spectroplot_hip.node'))
+        let warm = 1, calm = 0, fresh = addon.poolStats().fresh
+        while (warm < 12 || (calm < 24 && warm < 400)) {
+            await ask(worker, m)
+            warm++
+            const f = addon.poolStats().fresh
+            calm = f === fresh ? calm + 1 : 0
+            fresh = f
+        }
         const reps = 24
         let t0 = process.hrtime.bigint()
         let reply
@@ -60,6 +70,7 @@ async function main() {
             same = Buffer.compare(Buffer.from(ref.imageData.data.buffer), Buffer.from(reply.imageData.data.buffer)) === 0
         }
         rows.push({ name, format, samples: 2 ** log2s, n, request_buffer: pinned ? 'page-locked' : 'pageable', ms_per_message: gpu_ms, first_message_ms: cold_ms,
+            warmup_messages: warm,
             msamples_per_s: 2 ** log2s / gpu_ms / 1e3, js_worker_ms: cpu_ms, images_identical: same })
         if (!json) console.log(`${name}: ${format} 2^${log2s} samples, n=${n}: HipWorker ${gpu_ms.toFixed(2)} ms per message` +
             (cpu_ms ? `, JS worker ${cpu_ms.toFixed(0)} ms (x${(cpu_ms / gpu_ms).toFixed(0)}), images identical: ${same}` : ''))

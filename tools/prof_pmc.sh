@@ -25,7 +25,7 @@ i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
   if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
-  timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-rocprof "$@" > $OUT/pass$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-rocprof --no-extras "$@" < /dev/null > $OUT/pass$i.log 2>&1
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $ROOT/gpurun_out/pmc_${TAG}_summary.txt 2>&1
 cat $ROOT/gpurun_out/pmc_${TAG}_summary.txt
