@@ -171,6 +171,8 @@ def valu_roofline(config, kernel_us, frames):
     return {"bound": "f64 VALU issue", "f64_wave_insts": f64, "f64_wave_insts_per_frame_wave": f64 / max(frames, 1), "fused_f64_insts": g("SQ_INSTS_VALU_FMA_F64"),
             "valu_wave_insts": g("SQ_INSTS_VALU"), "cycles_per_inst": cost["f64"], "class_costs": cost,
             "class_counts": {"f64": f64, "cvt": cvt, "trans_f32": trans, "int": i32, "f32": f32, "other": other},
+            "fused_f64_note": "v_fma_f64 belongs to the IEEE divisions of the side outputs' software log10 and gauge scaling (a few per group of "
+                              "frames); the transform's multiplies and adds are all separate instructions",
             "floor_us": floor_us, "kernel_us": kernel_us, "frac": floor_us / kernel_us if kernel_us else None,
             "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r02_op_cost.txt" % (tag, config)}
 

@@ -505,8 +505,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                           const bool nt_rows) {
         const int dt = tid - t0;
         if (dt < 0) return;
-        if (a.rgba) {
-            if (!a.waterfall) {
+        // (the image's address, width and layout are read from the argument segment here, once per write-out, instead of sitting in
+        // SGPRs through every frame)
+        const LateArgs la = late_args();
+        uint8_t *const img = la->rgba;
+        const int img_width = la->width, img_waterfall = la->waterfall, img_fast = la->rgba_fast;
+        if (img) {
+            if (!img_waterfall) {
                 // spectrogram: image is n rows x width columns; row y holds bin (n/2 - y) mod n            worker.js:90,117
                 // The tile keeps a frame as the epilogue leaves it: 16 bytes per thread, byte e = bin tl + e*T.  A write-out item is
                 // one of a thread's four dwords (bins tl + (4*e4 + j)*T, j = 0..3) of 4 consecutive frames: four 16-byte stores in four
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         for (int j = 0; j < 4; j++)
 #pragma unroll
                             for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
-                    if (a.rgba_fast) {
+                    if (img_fast) {
                         // rows are 16-byte aligned, the width is a multiple of 4 and the image is below 4 GiB: 32-bit offsets from the
                         // uniform base (24-bit multiplies), no per-store checks
 #pragma unroll
@@ -545,13 +550,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const unsigned y = (y0 - (unsigned)(j * T)) & (N - 1);
-                                const unsigned off = (__umul24(y, (unsigned)a.width) + (unsigned)xa) * 4u;
+                                const unsigned off = (__umul24(y, (unsigned)img_width) + (unsigned)xa) * 4u;
                                 // written once, never read by this kernel: non-temporal where a group's row segments are whole
                                 // 128-byte lines, so that the image does not displace the capture's lines in L2 (measured: 2.5 % of the
                                 // kernel at n = 1024); shorter segments (large n) are pieces of lines that L2 has to merge with the
                                 // neighbouring groups' pieces (non-temporal there doubled the HBM traffic)
-                                if (nt_rows) store_nt(a.rgba + off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
-                                else *(uint4 *)(a.rgba + off) = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                                if (nt_rows) store_nt(img + off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                                else *(uint4 *)(img + off) = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             }
                         }
                         continue;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         for (int j = 0; j < 4; j++) {
                             const int i = i0v[u] + j * T;
                             const int y = (N / 2 - i) & (N - 1);
-                            uint8_t *dst = a.rgba + ((size_t)y * (size_t)a.width + (size_t)xa) * 4;
+                            uint8_t *dst = img + ((size_t)y * (size_t)img_width + (size_t)xa) * 4;
                             if (xa + 3 < a.x_end && (((size_t)dst & 15) == 0)) {
                                 *(uint4 *)dst = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
                             } else {
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         const int i = (c4 + k + N / 2 + 1) & (N - 1);
                         px[k] = s_lut[row[(i & (T - 1)) * 16 + (i >> (LOG2N - 4))]];
                     }
-                    uint8_t *dst = a.rgba + ((size_t)(a.width - 1 - xa) * N + (size_t)c4) * 4;
+                    uint8_t *dst = img + ((size_t)(img_width - 1 - xa) * N + (size_t)c4) * 4;
                     store_nt(dst, px[0], px[1], px[2], px[3]);
                 }
             }

@@ -55,7 +55,9 @@ def test_single_gpu_line_has_roofline_and_checks():
     assert t["outputs_equal"] is True and d["value_two_in_flight"] == t["value_two_in_flight"] > 0.8 * d["value"]
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]
     v = d["roofline_valu"]
-    assert v is None or (v["bound"] == "f64 VALU issue" and v["fused_f64_insts"] == 0 and 0.0 < v["frac"] < 1.0)
+    # (fused f64 instructions: only the divisions of the side outputs' log10 - a few thousand of 12.8 M f64 wave-instructions per launch;
+    # a fused butterfly graph would show up as millions)
+    assert v is None or (v["bound"] == "f64 VALU issue" and v["fused_f64_insts"] < 2e-3 * v["f64_wave_insts"] and 0.0 < v["frac"] < 1.0)
 
 
 @pytest.mark.parametrize("merge_every", [1, 3])
