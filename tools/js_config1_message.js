@@ -19,8 +19,15 @@ const msg = () => ({ block_norm: 1 / weight, gain: 6, range: 30, cmap, n, window
 function ask(worker, m) { return new Promise((resolve, reject) => { worker.onmessage = e => resolve(e.data); worker.onerror = reject; worker.postMessage(m, []) }) }
 async function run(label, sync, warm, reps) {
     const w = new HipWorker()
-    if (sync) w._render = function (m) {      // the variant that was tried: small requests on the calling thread
+    if (sync === true) w._render = function (m) {      // the variant that was tried: small requests on the calling thread
         return new Promise((resolve, reject) => { try { resolve(this._wrap(m, addon.renderSync(this._ctx, this._request(m)))) } catch (e) { reject(e) } })
+    }
+    if (sync === 'turn') w._render = function (m) {    // ... the same, but the reply is handed over in a new turn of the event loop
+        return new Promise((resolve, reject) => {
+            let r
+            try { r = this._wrap(m, addon.renderSync(this._ctx, this._request(m))) } catch (e) { reject(e); return }
+            setImmediate(() => resolve(r))
+        })
     }
     for (let i = 0; i < warm; i++) await ask(w, msg())
     const s0 = addon.poolStats()
@@ -36,5 +43,7 @@ async function main() {
     await run('sync,  short warm-up', true, 12, 24)
     await run('async, long warm-up', false, 200, 200)
     await run('sync,  long warm-up', true, 200, 200)
+    await run('sync + turn, short warm-up', 'turn', 12, 24)
+    await run('sync + turn, long warm-up', 'turn', 200, 200)
 }
 main().catch(e => { console.error(e); process.exit(1) })
