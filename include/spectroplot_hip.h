@@ -182,8 +182,9 @@ void sp_plan_destroy(sp_plan *plan);
  * d_bytes: device pointer to the raw capture (nbytes bytes, 16-byte aligned); reply: device pointers.
  * Every output of the reply is overwritten, histograms included: a reply holds the counts of its own request, as the
  * reference's worker returns fresh arrays (lib/worker.js:40-41); the caller sums the slices (lib/spectroplot.js:1229-1238).
- * The reply's arrays must live in DEVICE memory of the context's device: the frame-loop kernel clears them itself and its workgroups add
- * their shares with device atomics (one kernel per call; no separate finish launch for requests the frame loop covers).
+ * The reply's arrays must live in DEVICE memory of the context's device, c_hist / cb_hist / dbfs_minmax 8-byte aligned: the frame-loop
+ * kernel clears them itself and its workgroups add their shares with device atomics (one kernel per call; no separate finish launch
+ * for requests the frame loop covers).
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
 /*

@@ -651,6 +651,9 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     if (sample_count >= 2147483648.0 - (double)n)
         return fail(ctx, SP_ERR_UNSUPPORTED, "captures of 2^31 samples or more must be sliced (sample positions are int32)");
     if ((double)width * (double)n > 4e12) return fail(ctx, SP_ERR_UNSUPPORTED, "image too large");
+    // (the kernels add to these with 64-bit device atomics)
+    if ((((uintptr_t)out->c_hist | (uintptr_t)out->cb_hist | (uintptr_t)out->dbfs_minmax) & 7) != 0)
+        return fail(ctx, SP_ERR_INVALID_ARG, "reply: c_hist, cb_hist and dbfs_minmax must be 8-byte aligned");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
@@ -701,7 +704,7 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         SP_HIP(ctx, hipMemcpyAsync((char *)ctx->partial.p + 16, mm_init, sizeof mm_init, hipMemcpyHostToDevice, s));
         SP_HIP(ctx, hipStreamSynchronize(s));
     }
-    ctx->acc_dirty = true;   // until the finish kernel of this request has been queued
+    ctx->acc_dirty = true;   // until this request's last launch (k_frames) or its finish kernel (scratch path) has been queued
 
     spk::FrameArgs a{};
     a.bytes = (const uint8_t *)d_bytes;
@@ -994,7 +997,7 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
         }
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render streams");
     }
-    // (nothing to clear: the finish kernel overwrites every histogram count, both range values and every gauge byte)
+    // (nothing to clear: the kernels overwrite every histogram count, both range values and every gauge byte)
     if (chunks == 1) {
         if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");

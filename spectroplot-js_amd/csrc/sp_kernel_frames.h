@@ -16,14 +16,19 @@
 //   * epilogue: colour index and centi-bel level are floor(a + b*log2(|X|^2)) in f32; a lane is sent to the exact edge tables
 //     only if its f32 value lies within a proven error margin of an integer (a few lanes in ten thousand), so the common path has
 //     no LDS read and no f64 compare; one histogram atomic per pixel on the merged cell (colour index + level), which the
-//     finish kernel turns back into the two histograms; one colour byte per pixel into an LDS tile [frame][bin]; frame extremes of
-//     |X|^2 by LDS integer atomics on the bit patterns;
+//     workgroup turns back into the two histograms at its end; one colour byte per pixel into an LDS tile [frame][bin]; frame
+//     extremes of |X|^2 by LDS integer atomics on the bit patterns;
 //   * after a group of frames the workgroup writes the tile out through the RGBA LUT as 16-byte stores (128-byte row segments in
 //     spectrogram layout, whole rows in waterfall layout), in two slices around the passes of the next group's first frame;
 //   * n >= 2048 (a frame spans several waves): the waves of a frame meet through an LDS counter, announced early and waited for
 //     late where the dataflow allows, instead of the workgroup barrier;
 //   * the workgroup's last write-out is split between the first and the second waves of the SIMDs (n = 1024): the first ones
-//     finish ~7 us earlier and write their half meanwhile.
+//     finish ~7 us earlier and write their half meanwhile;
+//   * the request's side outputs come from this kernel too - one launch per sp_plan_execute: the gauges of a group of frames are
+//     evaluated (the reference's software log10, three per frame) by two waves inside the next group, where the first waves of the
+//     SIMDs have slack; at its end every workgroup adds its own share of the two histograms and of the dBfs range to the reply with
+//     fire-and-forget atomics (workgroup 0 has cleared the reply and published the request's number), so no workgroup waits for
+//     another and nothing makes a dependent trip to memory (a last-workgroup ticket costs three: profiles/r04_experiments.txt).
 // Measured alternatives (three waves per SIMD, two workgroups per CU, LDS-DMA input, other batch / slice / chain counts) are recorded in
 // DESIGN.md section 6.2; the cost-attribution switches and per-wave clock stamps that produced profiles/ live in
 // tools/experiments/frames_instrumentation.patch (tools/build_variant.sh applies it), not here.
