@@ -58,4 +58,6 @@ function main(argv) {
         })
 }
 
-main(process.argv.slice(2)).catch(e => { console.error(e.message || e); process.exit(1) })
+// (an explicit exit: Node 12 can crash while it tears its environment down when finalizers of collected reply buffers are
+// still queued - after all output, but with status 139; process.exit() does not take that path)
+main(process.argv.slice(2)).then(() => process.exit(0), e => { console.error(e.message || e); process.exit(1) })

@@ -6,7 +6,7 @@
  * Un-rendered columns stay zero, as on the reference's canvas.
  */
 const path = require('path')
-const { HipWorker, packLut } = require('./hip_worker.js')
+const { HipWorker, packLut, plainArray } = require('./hip_worker.js')
 
 function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplot_hip.node')) }
 
@@ -104,7 +104,7 @@ function renderOnGroup(a, o, q) {
         groups.set(q.workers, entry)
     }
     const g = entry.handle
-    const windowc = q.w.window instanceof Float64Array ? q.w.window : Float64Array.from(q.w.window)
+    const windowc = q.w.window instanceof Float64Array ? q.w.window : new Float64Array(q.w.window)
     const req = { format: q.fmt.id, buffer: o.buffer, n: q.n, windowc, block_norm: q.block_norm, gain: q.gain, range: q.range,
         lut: packLut(q.cmap), width: q.width, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
     const run = () => new Promise((resolve, reject) => {
@@ -117,7 +117,7 @@ function renderOnGroup(a, o, q) {
                 replies.push({ offset: lo, gauge_mins: gm.subarray(lo, hi), gauge_maxs: gx.subarray(lo, hi), gauge_amps: ga.subarray(lo, hi), imageData: null })
             }
             resolve({ data: new Uint8ClampedArray(r.rgba), width: o.waterfall ? q.n : q.width, height: o.waterfall ? q.width : q.n,
-                c_hist: Array.from(r.c_hist), cB_hist: Array.from(r.cB_hist), dBfs_min: r.dBfs_min, dBfs_max: r.dBfs_max,
+                c_hist: plainArray(r.c_hist), cB_hist: plainArray(r.cB_hist), dBfs_min: r.dBfs_min, dBfs_max: r.dBfs_max,
                 sliceWidth: q.sliceWidth, replies, transport: r.transport, members: r.members })
         })
     })

@@ -53,4 +53,6 @@ async function main() {
     console.log(`config 5 at full size through renderSliced ok: ${workers} slices x ${m.sliceWidth} frames, ${(4 * width * n / 2 ** 30).toFixed(1)} GiB of RGBA, ` +
         `generate ${t1 - t0} ms, render ${t2 - t1} ms`)
 }
-main().catch(e => { console.error(e); process.exit(1) })
+// (an explicit exit: Node 12 can crash while it tears its environment down when finalizers of collected reply buffers are
+// still queued - after all output, but with status 139; process.exit() does not take that path)
+main().then(() => process.exit(0), e => { console.error(e); process.exit(1) })
