@@ -146,6 +146,50 @@ def rocprof_kernel_us(argv_config):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def rocprof_hbm_bytes(argv_config):
+    """HBM bytes per launch of the frame-loop kernel from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass; no trace option next to --pmc), both in KiB, mean over the
+    second half of the kernel's launches of a short child run of this command; gfx950's FETCH_SIZE tallies the 128-byte requests of wide
+    coalesced streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte streaming stores.  None if rocprofv3 is
+    missing or a pass fails (the committed figure of profiles/ is reported then, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sp_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "40", "--warmup", "1000", "--no-cpu-baseline", "--no-e2e", "--no-rocprof", "--no-extras"] + argv_config
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                child.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in ("k_frames", "k_scratch_radix2")):
+                        vals.append(float(row["Counter_Value"]))
+            if len(vals) < 8:
+                return None
+            half = vals[len(vals) // 2:]
+            got[counter] = sum(half) / len(half)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"FETCH_SIZE_KB": got["FETCH_SIZE"], "WRITE_SIZE_KB": got["WRITE_SIZE"],
+            "hbm_bytes_per_launch": (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0}
+
+
 def valu_roofline(config, kernel_us, frames):
     """The resource that binds the frame loop in fact: VALU issue.  Counted wave-instructions per launch (rocprofv3
     --pmc, committed under profiles/) times the measured issue cost of their class with two waves per SIMD (profiles/r02_op_cost.txt),
@@ -215,6 +259,7 @@ def main():
     ap.add_argument("--rotate-all", action="store_true",
                     help="diagnostic: EVERY step of the run (spin-up, warm-up, timed region, the rocprofv3 child) cycles --rotate capture / "
                          "image sets instead of re-rendering one: the whole line is then measured on a working set beyond the Infinity Cache")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the kernel's HBM traffic (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the rotating-buffers and two-requests-in-flight legs (N = 1)")
     args = ap.parse_args()
 
@@ -222,13 +267,15 @@ def main():
         sys.exit(launch_ranks(sys.argv[1:], args.gpus))
 
     # dominant kernel's duration as rocprofv3 reports it: a short child run of this command, before this process touches the GPU
-    prof = prof_rot = None
+    prof = prof_rot = pmc = None
     if args.gpus == 1 and not args.no_rocprof and "WORLD_SIZE" not in os.environ:
         shape = ["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else []) + (["--no-rgba"] if args.no_rgba else [])
         prof = rocprof_kernel_us(shape + (["--rotate-all", "--rotate", str(args.rotate)] if args.rotate_all else []))
         if args.rotate >= 2 and not args.rotate_all and not args.no_extras:
             # the same kernel over K capture / image sets in rotation, the whole child run: is the default figure HBM bandwidth? (below)
             prof_rot = rocprof_kernel_us(shape + ["--rotate-all", "--rotate", str(args.rotate)])
+        if not args.no_pmc:
+            pmc = rocprof_hbm_bytes(shape)                   # two more short child runs: the kernel's HBM traffic, live
 
     import numpy as np
     import torch
@@ -540,7 +587,11 @@ def main():
     frames_per_s = world * W * args.steps / dt
 
     traffic, traffic_source = None, None
-    for tag in PROFILE_TAGS + ("r02",):
+    if pmc:
+        traffic = pmc["hbm_bytes_per_launch"]
+        traffic_source = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this command in this run: %.1f KiB x 2 (gfx950: wide "
+                          "streaming reads are tallied at half their bytes) + %.1f KiB" % (pmc["FETCH_SIZE_KB"], pmc["WRITE_SIZE_KB"]))
+    for tag in (PROFILE_TAGS + ("r02",)) if traffic is None else ():
         tfile = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (tag, args.config))
         if os.path.exists(tfile):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed, not live)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")

@@ -53,7 +53,9 @@ def test_single_gpu_line_has_roofline_and_checks():
     assert rot["sets"] == 3 and rot["working_set_MiB"] > 256 and 0.8 < rot["ratio"] < 1.3 and "kernel duration" in rot["verdict"]
     t = d["two_in_flight"]
     assert t["outputs_equal"] is True and d["value_two_in_flight"] == t["value_two_in_flight"] > 0.8 * d["value"]
-    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"] or "--pmc" in r["traffic_source"]
+    if r["traffic"] is not None:   # counter traffic within 0.9 ... 1.6 x the algorithmic bytes of a launch (config 5 re-reads: 1.25 x)
+        assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.6
     v = d["roofline_valu"]
     # (fused f64 instructions: only the divisions of the side outputs' log10 - a few thousand of 12.8 M f64 wave-instructions per launch;
     # a fused butterfly graph would show up as millions)
