@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--rotate-all", action="store_true",
                     help="diagnostic: EVERY step of the run (spin-up, warm-up, timed region, the rocprofv3 child) cycles --rotate capture / "
                          "image sets instead of re-rendering one: the whole line is then measured on a working set beyond the Infinity Cache")
+    ap.add_argument("--channel-mode", action="store_true", help="the reference's L/R split (channelMode: lib/fft_nayuki.js:103-119); not a BASELINE config")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the kernel's HBM traffic (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the rotating-buffers and two-requests-in-flight legs (N = 1)")
     args = ap.parse_args()
@@ -269,7 +270,7 @@ def main():
     # dominant kernel's duration as rocprofv3 reports it: a short child run of this command, before this process touches the GPU
     prof = prof_rot = pmc = None
     if args.gpus == 1 and not args.no_rocprof and "WORLD_SIZE" not in os.environ:
-        shape = ["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else []) + (["--no-rgba"] if args.no_rgba else [])
+        shape = ["--config", args.config, "--kernel", args.kernel] + (["--waterfall"] if args.waterfall else []) + (["--no-rgba"] if args.no_rgba else []) + (["--channel-mode"] if args.channel_mode else [])
         prof = rocprof_kernel_us(shape + (["--rotate-all", "--rotate", str(args.rotate)] if args.rotate_all else []))
         if args.rotate >= 2 and not args.rotate_all and not args.no_extras:
             # the same kernel over K capture / image sets in rotation, the whole child run: is the default figure HBM bandwidth? (below)
@@ -321,7 +322,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     win, weight = pkg.window(window, n)
     lut = load_cmap(cmap)
-    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, waterfall=args.waterfall)
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, channel_mode=args.channel_mode, waterfall=args.waterfall)
     if args.kernel != "auto":
         plan.force_kernel(args.kernel)
 
@@ -499,7 +500,7 @@ def main():
         # (CUs that have finished) overlaps the start of the next.  An extra figure, never the headline.
         try:
             ctx2 = pkg.Context(local_rank)
-            plan2 = ctx2.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, waterfall=args.waterfall)
+            plan2 = ctx2.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, channel_mode=args.channel_mode, waterfall=args.waterfall)
             if args.kernel != "auto":
                 plan2.force_kernel(args.kernel)
             rgba2 = torch.empty_like(rgba)
@@ -605,7 +606,7 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "spinup_steps_untimed": spinup, "cold": cold, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W
+            "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W + (", L/R split (channelMode)" if args.channel_mode else "")
                                    + (", %d capture / image sets in rotation" % len(rot_sets) if rot_sets else ""), "format": fmt, "n": n,
                        "samples_per_gpu": S, "frames_per_gpu": W, "window": window, "cmap": cmap,
                        "sharding": "contiguous time slice per GPU" if world > 1 else "single GPU",

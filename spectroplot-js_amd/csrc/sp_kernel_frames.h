@@ -314,7 +314,12 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     constexpr bool STAGED = PFB == 0;   // the generic loaders leave no registers for a whole pass's twiddles: read stage by stage
     // 8-byte samples at n >= 2048: a frame's samples are requested when it starts, not one frame ahead (the prefetch registers of
     // the next frame were what spilled there: cf32, n = 2048: 411 -> 358 us per 32 768 frames); its partner wave covers the latency
-    constexpr bool LATE_PF = PFB == 8 && LOG2N >= 11;
+    // The L/R split at n >= 2048 likewise (its 16 partner values on top of a frame's 32 spill ~32 registers with the prefetch kept): a
+    // spill reload waits for every vector-memory operation issued before it - in-order completion - i.e. for the prefetch itself.
+    // Requested at frame start, 12 spilled registers are left and configs 3 / 5 in channel mode take 12 % less time (1.39 -> 1.22 ms,
+    // 3.41 -> 2.96 ms).  (The taper from L2 per frame instead of registers: no spills at all, and slower than either.)
+    // (8-byte samples with the split at n = 1024: 22 spilled registers -> 0, 90.1 -> 88.0 us at config 2's shape)
+    constexpr bool LATE_PF = ((PFB == 8 || (CH && PFB != 0)) && LOG2N >= 11) || (CH && PFB == 8 && LOG2N == 10);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Layout lay = layout(N, a.lut_len, group_frames);
@@ -750,43 +755,54 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             // now register e of thread tl holds bin i = tl + e*T
 
             if constexpr (CH) {   // fft_nayuki.js:103-119, partner bin n-i fetched through LDS
-                double pp[16];
+                // (the partner values eight at a time where registers are short, n >= 2048: two LDS waits per component instead of one,
+                // and 16 registers fewer at the frame's register peak)
+                constexpr int PH = LOG2N >= 11 ? 8 : 16;
+                double pp[PH];
                 meet.wait();   // (announced after the last re-distribution's reads)
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = re[e];
                 meet();
 #pragma unroll
-                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+                for (int h = 0; h < 16; h += PH) {
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int i = tl + e * T;
-                    const double orr = re[e];
-                    if (i == 0) {
-                    } else if (i == N / 2) {
-                        re[e] = 0.0;
-                    } else if (i < N / 2) {
-                        re[e] = 0.5 * (orr + pp[e]);
-                    } else {
-                        re[e] = 0.5 * (-pp[e] + orr);
+                    for (int k = 0; k < PH; k++) pp[k] = xbuf[pad_idx((N - (tl + (h + k) * T)) & (N - 1))];
+#pragma unroll
+                    for (int k = 0; k < PH; k++) {
+                        const int e = h + k, i = tl + e * T;
+                        const double orr = re[e];
+                        if (i == 0) {
+                        } else if (i == N / 2) {
+                            re[e] = 0.0;
+                        } else if (i < N / 2) {
+                            re[e] = 0.5 * (orr + pp[k]);
+                        } else {
+                            re[e] = 0.5 * (-pp[k] + orr);
+                        }
                     }
+                    if (PH < 16) asm volatile("" ::: "memory");   // the second half's reads stay behind the first half's arithmetic
                 }
                 meet();
 #pragma unroll
                 for (int e = 0; e < 16; e++) xbuf[pad_idx(tl + e * T)] = im[e];
                 meet();
 #pragma unroll
-                for (int e = 0; e < 16; e++) pp[e] = xbuf[pad_idx((N - (tl + e * T)) & (N - 1))];
+                for (int h = 0; h < 16; h += PH) {
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int i = tl + e * T;
-                    const double oi = im[e];
-                    if (i == 0 || i == N / 2) {
-                        im[e] = 0.0;
-                    } else if (i < N / 2) {
-                        im[e] = 0.5 * (oi - pp[e]);
-                    } else {
-                        im[e] = 0.5 * (pp[e] + oi);
+                    for (int k = 0; k < PH; k++) pp[k] = xbuf[pad_idx((N - (tl + (h + k) * T)) & (N - 1))];
+#pragma unroll
+                    for (int k = 0; k < PH; k++) {
+                        const int e = h + k, i = tl + e * T;
+                        const double oi = im[e];
+                        if (i == 0 || i == N / 2) {
+                            im[e] = 0.0;
+                        } else if (i < N / 2) {
+                            im[e] = 0.5 * (oi - pp[k]);
+                        } else {
+                            im[e] = 0.5 * (pp[k] + oi);
+                        }
                     }
+                    if (PH < 16) asm volatile("" ::: "memory");
                 }
                 meet.arrive();   // for the next frame's first re-distribution
             }
