@@ -602,10 +602,14 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     const int xa = x0 + f;
                     if (xa >= a.x_end) continue;
                     const uint32_t gb = *(const uint32_t *)(s_tile + f * tile_pitch + tq * 16 + e4 * 4);
-                    const int c0 = tq + 4 * e4 * T + N / 2 - 1;
+                    // columns (i + n/2 - 1) mod n of bins i = tq + (4*e4 + j)*T: c0 + j*T without a wrap inside an item - except for
+                    // the one item per frame whose first pixel is the row's last (bin n/2): its other three start the row
+                    const int c0 = (tq + 4 * e4 * T + N / 2 - 1) & (N - 1);
                     uint32_t *const row = (uint32_t *)(img + (size_t)(img_width - 1 - xa) * N * 4);
+                    uint32_t *const p = row + (c0 == N - 1 ? -1 : c0);
+                    __builtin_nontemporal_store(s_lut[gb & 0xff], row + c0);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) __builtin_nontemporal_store(s_lut[(gb >> (8 * j)) & 0xff], row + ((c0 + j * T) & (N - 1)));
+                    for (int j = 1; j < 4; j++) __builtin_nontemporal_store(s_lut[(gb >> (8 * j)) & 0xff], p + j * T);
                 }
             }
         }
