@@ -33,6 +33,8 @@ CONFIGS = {
     "cfg2": ("CF32", 24, 1024, "blackmanHarris", "viridis", None, "16 MSample cf32, N=1024, Blackman-Harris, Viridis"),
     "cfg3": ("CS16", 28, 2048, "hann", "cube1", None, "256 MSample cs16, N=2048, Hann, Cube1"),
     "cfg4": ("CU8", 28, 1024, "blackmanHarris", "cube1", None, "256 MSample cu8 slice (1/8 of 2 GSample), N=1024, Blackman-Harris, Cube1"),
+    # (not a BASELINE config: config 5's shape with 4-byte samples)
+    "cfg5cs16": ("CS16", 26, 8192, "blackmanHarris", "cube1", (1 << 26) // 8192 * 8, "64 MSample cs16, N=8192, zoom x8, Blackman-Harris, Cube1"),
     "cfg5": ("CS12", 26, 8192, "blackmanHarris", "cube1", (1 << 26) // 8192 * 8, "64 MSample cs12, N=8192, zoom x8, Blackman-Harris, Cube1"),
     # not BASELINE configs: the 8-byte formats at the larger sizes (tuning runs of those kernel variants)
     "cf32_2048": ("CF32", 26, 2048, "blackmanHarris", "viridis", None, "64 MSample cf32, N=2048, Blackman-Harris, Viridis (not a BASELINE config)"),
