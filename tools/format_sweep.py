@@ -16,6 +16,14 @@ ctx = pkg.Context(0)
 lut = bench.load_cmap("viridis")
 L = len(lut)
 WIDTH = {"CU4": 1, "CS4": 1, "CU8": 2, "CS8": 2, "CU12": 3, "CS12": 3, "CU16": 4, "CS16": 4, "CU32": 8, "CS32": 8, "CF32": 8, "CU64": 16, "CS64": 16, "CF64": 16}
+# clock spin-up before the first measurement (an idle MI355X runs its first few thousand launches 5-15 % slower: bench.py does the same)
+_w, _ww = pkg.window("hann", 1024)
+_p = ctx.plan("CU8", 1024, _w, 1.0 / _ww, 6.0, 30.0, lut)
+_d = ctx.alloc(S * 2)
+_o = [ctx.alloc(max(s, 16)) for s in (4 * S, S // 1024, S // 1024, S // 1024, 8 * L, 8000, 16)]
+for _ in range(4000):
+    _p.execute(_d, S * 2, S // 1024, *_o)
+ctx.synchronize()
 print("us per launch over 2^%d samples (event pair, incl. ~6 us of dispatch latency); layout spectrogram, Blackman-Harris" % lg)
 print("%-6s" % "fmt" + "".join("%10s" % ("n=%d" % n) for n in SIZES) + "     channel mode: n=1024, n=2048")
 for fmt, sw in WIDTH.items():

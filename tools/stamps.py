@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave phase clocks of k_frames from a library built with -DSP_STAMPS (tools/build_variant.sh stamps -DSP_STAMPS).
-   SP_EXPERIMENT_KNOBS=1 SP_LIB_VARIANT=stamps python3 tools/stamps.py [cfg]"""
+   SP_EXPERIMENT_KNOBS=1 SP_LIB_VARIANT=stamps python3 tools/stamps.py [cfg | FORMAT:log2samples:n]"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,12 @@ import bench
 from __graft_entry__ import load_package
 pkg = load_package()
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-fmt, lg, n, window, cmap, frames, desc = bench.CONFIGS[cfg]
+if ":" in cfg:   # FORMAT:log2(samples):n, e.g. CU4:24:1024 (bytes per sample from the library's format table)
+    fmt, lg, n = cfg.split(":")[0], int(cfg.split(":")[1]), int(cfg.split(":")[2])
+    window, cmap, frames = "blackmanHarris", "viridis", None
+    bench.SAMPLE_WIDTH[fmt] = pkg.parse_format(fmt)[1]
+else:
+    fmt, lg, n, window, cmap, frames, desc = bench.CONFIGS[cfg]
 S = 1 << lg; sw = bench.SAMPLE_WIDTH[fmt]; W = frames if frames else S // n
 ctx = pkg.Context(0)
 win, weight = pkg.window(window, n)
