@@ -318,8 +318,9 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     // spill reload waits for every vector-memory operation issued before it - in-order completion - i.e. for the prefetch itself.
     // Requested at frame start, 12 spilled registers are left and configs 3 / 5 in channel mode take 12 % less time (1.39 -> 1.22 ms,
     // 3.41 -> 2.96 ms).  (The taper from L2 per frame instead of registers: no spills at all, and slower than either.)
-    // (8-byte samples with the split at n = 1024: 22 spilled registers -> 0, 90.1 -> 88.0 us at config 2's shape)
-    constexpr bool LATE_PF = ((PFB == 8 || (CH && PFB != 0)) && LOG2N >= 11) || (CH && PFB == 8 && LOG2N == 10);
+    // (8-byte samples with the split at n = 1024: 22 spilled registers -> 0, 90.1 -> 88.0 us at config 2's shape; n = 512: 14 -> 0,
+    // 81.6 -> 77.8 us per 2^24 samples; n = 256, 6 spilled registers, is 2 % faster with the prefetch and keeps it)
+    constexpr bool LATE_PF = ((PFB == 8 || (CH && PFB != 0)) && LOG2N >= 11) || (CH && PFB == 8 && LOG2N >= 9);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Layout lay = layout(N, a.lut_len, group_frames);
