@@ -369,7 +369,11 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     // n = 1024, 32-frame groups: the first / second waves of the SIMDs each take one half of a group's frames
     const bool HALVES = T == 64 && group_frames == 32;
     const int fs0 = HALVES ? (fs / (FPB / 2)) * (group_frames / 2) + fs % (FPB / 2) : fs;     // the slot's frame in a group's first round
-    if (PF && !LATE_PF && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
+    // n <= 1024 requests the first frame's samples behind the table loads, below (config 2: -1.6 us per launch); above, where the tables
+    // are a quarter of the size and the taper goes to registers after them, the old order measures the same (n = 2048) or 1.3 % better
+    // (n = 8192: the other order shifts the loop's register allocation)
+    constexpr bool REQ_AFTER_TABLES = PF && !LATE_PF && LOG2N <= 10;
+    if (PF && !LATE_PF && !REQ_AFTER_TABLES && xcd * chunk + lane_in_xcd < g_end) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
 
     // workgroup 0's first wave owns the reply's initial state in the first launch of a request (below)
     const bool owner = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(tid >> 6) == 0 && a.first;   // (wave-uniform)
@@ -421,6 +425,10 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             if (tid < 2 && out_mm)
                 __hip_atomic_store(out_mm + tid, tid ? 0xc069000000000000ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // -200.0, 0.0
         }
+        // The first frame's samples are requested BEHIND the table loads (vector-memory operations complete in order: requested ahead of
+        // them, the wait for the tables - L2 hits - was a wait for the samples from HBM), and unconditionally (a frame past the end is
+        // clamped), so that the compiler can count the 16 younger loads in that wait: s_waitcnt vmcnt(16).
+        if constexpr (REQ_AFTER_TABLES) request(a.frame0 + (xcd * chunk + lane_in_xcd) * group_frames + fs0);
         // what needs no table is set up while the loads are in flight (a table load takes ~2.3 us at the start of a launch)
         for (int i = tid; i < a.cells; i += kThreads) s_cells[i] = 0;
         if (tid < 8) s_done[tid] = 0;
