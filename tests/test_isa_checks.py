@@ -87,3 +87,38 @@ def test_the_prefetching_iq_variants_of_the_frame_loop_use_no_scratch_memory():
                 spill = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", blk).group(1))
                 assert priv == 0 and spill == 0, (m.group(0), priv, spill)
     assert seen == 8 * 5           # eight sizes x five prefetch widths
+
+
+def test_the_prologue_waits_for_its_tables_not_for_the_first_frames_samples():
+    """n <= 1024, prefetching variants: the first frame's 16 sample loads are issued BEHIND the table loads and the wait in front of the
+    LDS table stores counts them (s_waitcnt vmcnt(16)).  Vector-memory operations complete in order: a vmcnt(0) there - the samples
+    requested ahead of the tables, or a request the compiler cannot count - makes the table wait a wait for HBM (+1.5 us per launch)."""
+    import re
+    objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "frames_*.o")))
+    if len(objs) < 8:
+        build()
+        objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "frames_*.o")))
+    c = _checker()
+    seen = 0
+    for o in objs:
+        m = re.search(r"frames_(\d+)\.o$", o)
+        if int(m.group(1)) > 10:
+            continue
+        kernel, waits = None, []
+        for ln in c.disassemble(o):
+            h = re.match(r"[0-9a-f]+ <_ZN4spk28k_framesILi(\d+)ELb([01])ELi(\d+)E", ln)
+            if h:
+                kernel, waits = h.groups(), []
+                continue
+            if kernel is None:
+                continue
+            t = ln.replace("\t", " ")
+            w = re.search(r" s_waitcnt .*vmcnt\((\d+)\)", t)
+            if w:
+                waits.append(int(w.group(1)))
+            if " s_barrier" in t:                      # the prologue's barrier: everything before it is the prologue
+                if kernel[2] != "0" and kernel[1] == "0":
+                    assert waits and waits[-1] == 16 and 0 not in waits, (kernel, waits)
+                    seen += 1
+                kernel = None
+    assert seen >= 5 * 5          # five prefetch widths at n = 64 .. 1024
