@@ -51,6 +51,7 @@ ghz = a[:, :, 9].mean() / (a[:, :, 10].mean() * 10.0)
 print("  whole wave: %.0f shader cycles = %.2f us of the 100 MHz clock -> %.2f GHz; prologue %.0f cycles (%.2f us), loop %.0f (%.2f us), tail %.0f (%.2f us)"
       % (a[:, :, 9].mean(), a[:, :, 10].mean() / 100.0, ghz, a[:, :, 8].mean(), a[:, :, 8].mean() / ghz / 1e3, tot, tot / ghz / 1e3,
          (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean(), (a[:, :, 9] - a[:, :, 8] - a[:, :, 6]).mean() / ghz / 1e3))
+# (n <= 1024: the first request is issued behind the table loads, so the argument segment's first fetch and the request's issue show in the second figure)
 print("  prologue: arguments + first request %.0f cycles, tables arrive %.0f, zeroing + barrier %.0f" % (a[:, :, 16].mean(), a[:, :, 17].mean(), a[:, :, 18].mean()))
 print("  inside the frame meetings (n >= 2048): %.0f cycles per wave = %.1f %% of the loop; by wave:" % (a[:, :, 19].mean(), 100 * a[:, :, 19].mean() / tot), np.round(a[:, :, 19].mean(axis=0)))
 hw = a[:, :, 13].astype(np.int64)
