@@ -12,14 +12,19 @@
 //     frames after one f32 multiply-add per raw word), the ones whose sine is exactly 1 skip two products always;
 //   * the re-distribution between passes goes through a padded, wave-private LDS buffer; at n = 512 / 1024 the second one is a
 //     register transpose (v_permlane16_swap / v_permlane32_swap: what it costs the VALU the LDS round trip costs the LDS pipe);
-//   * input: the raw words of the NEXT frame are requested right after the current frame is decoded (1-, 2-, 3-, 4-, 8-byte samples);
+//   * input: the raw words of the NEXT frame are requested right after the current frame is decoded (1-, 2-, 3-, 4-, 8-byte samples).
+//     One rule follows from the chip completing a wave's vector-memory operations IN ORDER: whatever waits for a younger operation - a
+//     reload of a spilled register, a table load - waits for that prefetch too.  So no prefetching variant may spill inside the loop
+//     (tests/test_isa_checks.py); the variants that would (8-byte samples at n >= 2048; the L/R split at n >= 2048 and with 8-byte samples
+//     from n = 512) request a frame's samples when it starts; and the prologue requests the first frame BEHIND its table loads (n <= 1024);
 //   * epilogue: colour index and centi-bel level are floor(a + b*log2(|X|^2)) in f32; a lane is sent to the exact edge tables
 //     only if its f32 value lies within a proven error margin of an integer (a few lanes in ten thousand), so the common path has
 //     no LDS read and no f64 compare; one histogram atomic per pixel on the merged cell (colour index + level), which the
 //     workgroup turns back into the two histograms at its end; one colour byte per pixel into an LDS tile [frame][bin]; frame
 //     extremes of |X|^2 by LDS integer atomics on the bit patterns;
-//   * after a group of frames the workgroup writes the tile out through the RGBA LUT as 16-byte stores (128-byte row segments in
-//     spectrogram layout, whole rows in waterfall layout), in two slices around the passes of the next group's first frame;
+//   * after a group of frames the workgroup writes the tile out through the RGBA LUT, in two slices around the passes of the next
+//     group's first frame: 16-byte stores, 128-byte row segments in spectrogram layout; in waterfall layout one tile dword per item as
+//     four dword stores, 256 contiguous bytes of an image row per wave and store instruction;
 //   * n >= 2048 (a frame spans several waves): the waves of a frame meet through an LDS counter, announced early and waited for
 //     late where the dataflow allows, instead of the workgroup barrier;
 //   * the workgroup's last write-out is split between the first and the second waves of the SIMDs (n = 1024): the first ones
@@ -38,8 +43,6 @@
 #include <cstdio>
 
 #include "sp_frame_parts.h"
-
-// experiment switches of the large-n layout (defaults = the shipped kernel)
 
 namespace spk2 {
 
