@@ -148,6 +148,23 @@ def rocprof_kernel_us(argv_config):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def pmc_counter_mean(directory, counter):
+    """Mean of one counter over the second half of the frame-loop kernel's dispatches in rocprofv3's counter_collection CSVs under
+    `directory` (one row per dispatch and counter: Kernel_Name, Counter_Name, Counter_Value), None with fewer than 8 dispatches."""
+    import csv
+    import glob
+    vals = []
+    for f in sorted(glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in ("k_frames", "k_scratch_radix2")):
+                    vals.append(float(row["Counter_Value"]))
+    if len(vals) < 8:
+        return None
+    half = vals[len(vals) // 2:]
+    return sum(half) / len(half)
+
+
 def rocprof_hbm_bytes(argv_config):
     """HBM bytes per launch of the frame-loop kernel from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
     WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass; no trace option next to --pmc), both in KiB, mean over the
@@ -175,15 +192,9 @@ def rocprof_hbm_bytes(argv_config):
                 os.killpg(child.pid, signal.SIGKILL)
                 child.wait()
                 return None
-            vals = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in ("k_frames", "k_scratch_radix2")):
-                        vals.append(float(row["Counter_Value"]))
-            if len(vals) < 8:
+            got[counter] = pmc_counter_mean(d, counter)
+            if got[counter] is None:
                 return None
-            half = vals[len(vals) // 2:]
-            got[counter] = sum(half) / len(half)
         except Exception:
             return None
         finally:
