@@ -1,10 +1,10 @@
 #!/bin/bash
 # Same-box A/B of library variants (tools/build_variant.sh) on one kernel: rocprofv3 kernel-trace average of the frame-loop kernel
-#   tools/ab_variants.sh "<variant> ..." [config] [kernel] [extra bench args]     ("-" = the library in lib/)
+#   [REPS=n] tools/ab_variants.sh "<variant> ..." [config] [kernel] [extra bench args]     ("-" = the library in lib/; default 2 repetitions)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${2:-cfg2}; K=${3:-frames}
 cd /tmp && export TMPDIR=/tmp SP_EXPERIMENT_KNOBS=1
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in $1; do
   if [ "$v" = "-" ]; then unset SP_LIB_VARIANT; else export SP_LIB_VARIANT=$v; fi
   if [ "$v" != "-" ] && [ ! -f $ROOT/spectroplot-js_amd/lib/variants/$v.so ]; then echo "variant $v: not built, skipped"; continue; fi
