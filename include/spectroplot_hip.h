@@ -17,6 +17,7 @@
  *   sp_twiddles              lib/fft_nayuki.js:42-47    cos/sin tables (exposed for tests)
  *   sp_plan_create           lib/worker.js:30-62        per-request constants + the cached FFT object
  *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
+ *   sp_render_strip          lib/worker.js:23-156 + lib/spectroplot.js:1241-1244   the same, written into the strip's band of the caller's image
  *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
  *   sp_merge_replies         lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
  *   sp_place_strips          lib/spectroplot.js:1241-1244   the caller's putImageData of every slice's strip, on the device
@@ -146,6 +147,14 @@ int sp_context_synchronize(sp_context *ctx);
  * reference caches its FFT object (lib/worker.js:59-62).
  */
 int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+/*
+ * The same render delivered where the caller's merge would put it (lib/spectroplot.js:1241-1244, putImageData(strip, offset, 0)):
+ * reply->rgba points at the strip's first pixel INSIDE an image of image_width >= width frames - spectrogram layout: column `offset` of
+ * row 0, rows 4 * image_width bytes apart; waterfall layout: the first of the strip's `width` contiguous rows.  Everything else as
+ * sp_render (sp_render is sp_render_strip with image_width = width).
+ */
+int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
+                    int32_t image_width);
 
 /*
  * The same with the request given by names, as the reference's caller assembles its message from options
@@ -215,14 +224,44 @@ int sp_place_strips(sp_context *ctx, uint8_t *d_image, const uint8_t *d_strips, 
  * `reply` holds host pointers: rgba [4 * width * n] (columns beyond members * sliceWidth are zero, as the caller's canvas leaves them),
  * c_hist / cb_hist / dbfs_minmax merged over the slices (starting from 0 and (0, -200), :1125-1126), gauge_* [width] with slice r's
  * gauges at [r * sliceWidth, (r + 1) * sliceWidth).  Any may be NULL.  Plans are kept while the request's constants repeat.
- * sp_group_transport names what moved the strips in the last render: "none" (one member), "rccl" or "peer".
+ * sp_group_transport names what moved the strips in the last render: "none" (one member), "rccl", "peer" or "host".
+ *
+ * sp_group_render_ex chooses where the strips meet (sp_group_render = SP_GROUP_GATHER_DEVICE):
+ *   SP_GROUP_GATHER_DEVICE  as above: the image is assembled in the root's HBM and comes back over the root's host link in one copy.
+ *                           Peer copies and waterfall-layout RCCL receives land in the image itself (root memory = the image); the
+ *                           spectrogram layout under RCCL receives whole strips next to it and re-tiles them on the root.  The mode
+ *                           for an image that is consumed on the root GPU, and the one that exercises the xGMI gather.
+ *   SP_GROUP_GATHER_HOST    the image is bound for the host anyway, so nothing is gathered on a device: every member runs the chunked
+ *                           sp_render_strip pipeline on its own slice and copies its strip straight into its band of `reply->rgba`
+ *                           over its OWN host link (N links side by side instead of one); histograms, dBfs range and gauges are
+ *                           merged on the host.  transport = "host".  The mode to use whenever reply->rgba is host memory.
+ * Environment (read when the group is created):
+ *   SPECTROPLOT_HIP_NO_RCCL=1      never use RCCL
+ *   SPECTROPLOT_HIP_FORCE_RCCL=1   use RCCL whatever the member list looks like: a one-member group then moves the root's own strip and
+ *                                  record through a grouped self ncclSend / ncclRecv (what a one-GPU box can execute of the transport);
+ *                                  members sharing a device make ncclCommInitAll fail, which falls back to peer copies like any other
+ *                                  RCCL failure
+ *   SPECTROPLOT_HIP_RCCL_LIB=path  the library to dlopen instead of librccl.so.1
+ * An RCCL failure (library missing, init, send / receive, group end) never fails the render: the member streams are drained, the
+ * communicators are aborted, the render is completed with peer copies, RCCL is not tried again on this group, and
+ * sp_group_transport_note tells what happened (also: peer access that could not be enabled).
+ * sp_group_last_timings: milliseconds of the last render's phases - upload + render (slowest member, device events), gather (from the
+ * root's render to the assembled image on the root), download (root to host); in host mode the first is the slowest member's whole
+ * sp_render_strip by the host clock and the other two are 0.
  */
 typedef struct sp_group sp_group;
+enum sp_group_gather { SP_GROUP_GATHER_DEVICE = 0, SP_GROUP_GATHER_HOST = 1 };
 int sp_group_create(const int32_t *devices, int32_t count, sp_group **group);
 void sp_group_destroy(sp_group *group);
 int sp_group_size(const sp_group *group);
 int sp_group_render(sp_group *group, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply);
+int sp_group_render_ex(sp_group *group, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
+                       int32_t gather);
 const char *sp_group_transport(const sp_group *group);
+const char *sp_group_transport_note(const sp_group *group);
+int sp_group_last_timings(const sp_group *group, double *render_ms, double *gather_ms, double *download_ms);
+/* Device bytes the root member holds for the gather beyond its own strip (image + staging), after the last render. */
+int sp_group_root_bytes(const sp_group *group, size_t *image_bytes, size_t *staging_bytes);
 const char *sp_group_last_error(const sp_group *group);
 
 /* Name of the kernel sp_plan_execute launches: "frames" (64 <= n <= 8192, LUT <= 256 entries) or "scratch_radix2" (everything else). */

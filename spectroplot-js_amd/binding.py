@@ -119,6 +119,13 @@ class Library:
         L.sp_group_transport.argtypes = [vp]
         L.sp_group_last_error.restype = C.c_char_p
         L.sp_group_last_error.argtypes = [vp]
+        if hasattr(L, "sp_group_render_ex"):
+            L.sp_group_render_ex.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply), i32]
+            L.sp_group_transport_note.restype = C.c_char_p
+            L.sp_group_transport_note.argtypes = [vp]
+            L.sp_group_last_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
+            L.sp_group_root_bytes.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+            L.sp_render_strip.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply), i32]
         L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
 
     @classmethod
@@ -385,9 +392,28 @@ class Group:
     def transport(self):
         return self.lib.L.sp_group_transport(self.h).decode()
 
-    def render(self, fmt, data, n, windowc, block_norm, gain, rng, lut, width, channel_mode=False, waterfall=False):
+    def transport_note(self):
+        """Why the last transport was chosen when it was not the first choice (RCCL failures, peer access that could not be enabled)."""
+        return self.lib.L.sp_group_transport_note(self.h).decode()
+
+    def timings(self):
+        """Milliseconds of the last render's phases: (upload + render of the slowest member, gather on the root, download)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.lib.L.sp_group_last_timings(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def root_bytes(self):
+        """(image bytes, staging bytes) the root member holds on its device for the gather."""
+        a, b = C.c_size_t(), C.c_size_t()
+        self.lib.L.sp_group_root_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def render(self, fmt, data, n, windowc, block_norm, gain, rng, lut, width, channel_mode=False, waterfall=False, gather="device",
+               dirty=None):
         """Same argument meaning as Context.render; the reply is the caller's MERGED result (`rgba` the whole image, histograms and
-        dBfs range over all slices, gauges with slice r's at [r * slice_width, (r + 1) * slice_width))."""
+        dBfs range over all slices, gauges with slice r's at [r * slice_width, (r + 1) * slice_width)).  gather: "device" (strips meet
+        in the root's HBM: RCCL / peer copies) or "host" (every member writes its band of the host image over its own link).
+        dirty: a byte value the output buffers are pre-filled with (tests: what no slice draws must come back cleared)."""
         fid, _ = parse_format(fmt)
         data = np.ascontiguousarray(data, dtype=np.uint8)
         req, keep = _make_request(fid, n, windowc, block_norm, gain, rng, lut, channel_mode, waterfall)
@@ -400,7 +426,11 @@ class Group:
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         rep = _Reply(p(out["rgba"]), p(out["gauge_mins"]), p(out["gauge_maxs"]), p(out["gauge_amps"]), p(out["c_hist"]),
                      p(out["cB_hist"]), p(mm))
-        status = self.lib.L.sp_group_render(self.h, C.byref(req), p(data), data.size, W, C.byref(rep))
+        if dirty is not None:
+            for k in ("rgba", "gauge_mins", "gauge_maxs", "gauge_amps"):
+                out[k][:] = dirty
+        mode = {"device": 0, "host": 1}[gather]
+        status = self.lib.L.sp_group_render_ex(self.h, C.byref(req), p(data), data.size, W, C.byref(rep), mode)
         if status:
             raise SpectroplotError(status, self.lib.L.sp_group_last_error(self.h).decode() or self.lib.L.sp_status_string(status).decode())
         out["dBfs_min"], out["dBfs_max"] = float(mm[0]), float(mm[1])

@@ -932,12 +932,16 @@ static bool same_request(const sp_plan *p, const sp_request *r)
     return memcmp(p->lut.data(), r->lut_rgb, 3 * (size_t)r->lut_len) == 0;
 }
 
-extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply)
+// sp_render / sp_render_strip: `image_width` is the width in frames of the image reply->rgba points into (the strip's own width for
+// sp_render); it only matters for the spectrogram layout, whose rows are image_width pixels apart.
+static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
+                       int32_t image_width)
 {
     if (!ctx || !reply) return SP_ERR_INVALID_ARG;
     int rc = validate_request(ctx, req);
     if (rc) return rc;
     if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
+    if (image_width < width) return fail(ctx, SP_ERR_INVALID_ARG, "image_width < width");
     if (nbytes && !bytes) return fail(ctx, SP_ERR_INVALID_ARG, "bytes is null");
     // the reference constructs its typed view before anything else (worker.js:24)
     if (nbytes % (size_t)spfmt::describe(req->format).elem)
@@ -955,6 +959,7 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
 
     const size_t W = (size_t)width, n = (size_t)req->n, L = (size_t)req->lut_len;
     const size_t rgba_bytes = 4 * W * n;
+    const size_t host_pitch = req->waterfall ? 4 * n : 4 * (size_t)image_width;   // bytes between rows of the caller's image
     rc = ctx->in_bytes.reserve(nbytes + 16);
     if (!rc) rc = ctx->out_rgba.reserve(rgba_bytes + 16);
     // small outputs: [c_hist L u64][cb_hist 1000 u64][minmax 2 f64][gauges 3*W u8]
@@ -1035,7 +1040,7 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
                     e = hipMemcpyAsync(reply->rgba + off, (char *)ctx->out_rgba.p + off, 4 * n * (size_t)(x1 - x0), hipMemcpyDeviceToHost,
                                        ctx->copy_out);
                 } else {                // columns x0 .. x1-1 of every row
-                    e = hipMemcpy2DAsync(reply->rgba + 4 * (size_t)x0, 4 * W, (char *)ctx->out_rgba.p + 4 * (size_t)x0, 4 * W,
+                    e = hipMemcpy2DAsync(reply->rgba + 4 * (size_t)x0, host_pitch, (char *)ctx->out_rgba.p + 4 * (size_t)x0, 4 * W,
                                          4 * (size_t)(x1 - x0), n, hipMemcpyDeviceToHost, ctx->copy_out);
                 }
                 if (e != hipSuccess) break;
@@ -1053,7 +1058,11 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     auto down = [&](void *dst, const void *src, size_t bytes_) {
         if (dst && bytes_ && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, s);
     };
-    if (chunks == 1) down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
+    if (chunks == 1) {
+        if (req->waterfall || host_pitch == 4 * W) down(reply->rgba, ctx->out_rgba.p, rgba_bytes);
+        else if (reply->rgba && rgba_bytes && e == hipSuccess)   // a column band of a wider image
+            e = hipMemcpy2DAsync(reply->rgba, host_pitch, ctx->out_rgba.p, 4 * W, 4 * W, n, hipMemcpyDeviceToHost, s);
+    }
     // the six small outputs sit side by side on the device: one copy into the context's page-locked block, handed out from there
     // (six separate copies into pageable memory cost more than the kernels of a small request)
     down(ctx->host_small.p, small.p, small_bytes);
@@ -1072,6 +1081,17 @@ extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *
     if (reply->gauge_maxs) memcpy(reply->gauge_maxs, h_g + W, W);
     if (reply->gauge_amps) memcpy(reply->gauge_amps, h_g + 2 * W, W);
     return SP_OK;
+}
+
+extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply)
+{
+    return render_host(ctx, req, bytes, nbytes, width, reply, width);
+}
+
+extern "C" int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width,
+                               const sp_reply *reply, int32_t image_width)
+{
+    return render_host(ctx, req, bytes, nbytes, width, reply, image_width);
 }
 
 // ------------------------------------------------------------------------------------------------- requests by name

@@ -14,16 +14,22 @@ function native() { return require(path.join(__dirname, '..', 'lib', 'spectroplo
  * With `byName: true`, `window` and `cmap` are option names (any spelling the reference's lookup accepts) and the slices go to the
  * workers as named requests (HipWorker.renderNamed -> sp_render_named): taper, block_norm and the end-forced colour map are evaluated
  * inside the library, once per worker while the names repeat.
- * With `device: true` the whole sliced render is ONE native call (sp_group_render): slice r is rendered on group member r - member r on
- * GPU r modulo the visible GPUs - the strips travel to the root GPU device to device (RCCL over xGMI between distinct GPUs, peer copies
- * otherwise) and are merged there (sp_merge_replies, sp_place_strips); the merged image crosses the host link once.  The result has the
- * same fields; `replies` then carry the slices' offsets and gauges only (their strips never existed in host memory) and `transport`
- * names what moved the strips.  Groups are kept per worker count (renderSliced.closeGroups() releases them).
+ * With `device: true` the whole sliced render is ONE native call (sp_group_render_ex): slice r is rendered on group member r - member r
+ * on GPU r modulo the visible GPUs.  `gather` says where the strips meet:
+ *   'device' (default)  on the root GPU, device to device (RCCL over xGMI between distinct GPUs, peer copies otherwise), merged there;
+ *                       the merged image crosses the root's host link once.  For an image that is wanted on the root GPU, and to
+ *                       exercise / measure the xGMI gather.
+ *   'host'              every member copies its strip straight into its band of the result over its OWN host link (N links side by
+ *                       side) and the side outputs are merged on the host: what to use whenever the image is wanted in host memory.
+ * The result has the same fields; `replies` then carry the slices' offsets and gauges only (their strips never existed as separate
+ * host buffers), `transport` names what moved the strips ('none' | 'rccl' | 'peer' | 'host'), `transportNote` why it was not the first
+ * choice (an RCCL failure ends in peer copies, never in a failed render) and `timings` the phases' milliseconds.  Groups are kept per
+ * worker count (renderSliced.closeGroups() releases them).
  * With `merge: false` the strips are not copied into one image (`data` is null; `replies` hold them): an image of 2^31 bytes or more -
  * BASELINE config 5 is exactly 2^31 - is beyond what one typed array can hold under Node 12, as it is beyond one canvas.
  * @param {{buffer: ArrayBuffer, format: string, n: number, width: number, workers?: number, window?: string|{window, weight},
  *          cmap: number[][]|string, gain?: number, range?: number, channelMode?: boolean, waterfall?: boolean, byName?: boolean,
- *          merge?: boolean}} o
+ *          merge?: boolean, device?: boolean, gather?: 'device'|'host'}} o
  * @returns {Promise<{data: Uint8ClampedArray, width, height, c_hist, cB_hist, dBfs_min, dBfs_max, sliceWidth, replies}>}
  */
 function renderSliced(o, pool) {
@@ -106,7 +112,7 @@ function renderOnGroup(a, o, q) {
     const g = entry.handle
     const windowc = q.w.window instanceof Float64Array ? q.w.window : new Float64Array(q.w.window)
     const req = { format: q.fmt.id, buffer: o.buffer, n: q.n, windowc, block_norm: q.block_norm, gain: q.gain, range: q.range,
-        lut: packLut(q.cmap), width: q.width, channelMode: !!o.channelMode, waterfall: !!o.waterfall }
+        lut: packLut(q.cmap), width: q.width, channelMode: !!o.channelMode, waterfall: !!o.waterfall, gather: o.gather === 'host' ? 'host' : 'device' }
     const run = () => new Promise((resolve, reject) => {
         a.groupRender(g, req, (err, r) => {
             if (err) { reject(err); return }
@@ -118,7 +124,7 @@ function renderOnGroup(a, o, q) {
             }
             resolve({ data: new Uint8ClampedArray(r.rgba), width: o.waterfall ? q.n : q.width, height: o.waterfall ? q.width : q.n,
                 c_hist: plainArray(r.c_hist), cB_hist: plainArray(r.cB_hist), dBfs_min: r.dBfs_min, dBfs_max: r.dBfs_max,
-                sliceWidth: q.sliceWidth, replies, transport: r.transport, members: r.members })
+                sliceWidth: q.sliceWidth, replies, transport: r.transport, transportNote: r.transportNote, timings: r.timings, members: r.members })
         })
     })
     const p = entry.queue.then(run)

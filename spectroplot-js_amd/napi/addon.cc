@@ -30,7 +30,8 @@
 //   planCreations(handle)                          -> how many plans this context has built (sp_context_plan_creations)
 //   createGroup(devices: number[])                 -> external handle of an sp_group: one member context per listed device
 //   destroyGroup(handle)                           -> like destroyContext
-//   groupRender(handle, req, cb) / groupRenderSync(handle, req)   req as for render, `width` = frames of the WHOLE image:
+//   groupRender(handle, req, cb) / groupRenderSync(handle, req)   req as for render, `width` = frames of the WHOLE image, plus
+//       `gather`: 'device' (default) | 'host' (sp_group_render_ex); the result carries transport, transportNote and timings:
 //       sp_group_render - the caller's sliced render (lib/spectroplot.js:1206-1244) with the strips gathered device to device (RCCL or
 //       peer copies) and merged on the root; the reply is the merged result (rgba = the whole image, gauges [width]) plus
 //       {sliceWidth, members, transport: 'none' | 'rccl' | 'peer'}
@@ -220,6 +221,9 @@ struct Job {
     Ctx *owner = nullptr;
     sp_context *ctx = nullptr;
     sp_group *group = nullptr;   // a group handle's job
+    int32_t gather = SP_GROUP_GATHER_DEVICE;   // ... and where its strips meet (req.gather: 'device' | 'host')
+    std::string transport, note;
+    double t_render = 0, t_gather = 0, t_download = 0;
     sp_request req{};
     std::vector<double> window;
     std::vector<uint8_t> lut;
@@ -281,6 +285,7 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j, bool
     }
     get_named(env, req, "n", &v); napi_get_value_int32(env, v, &i32); j->req.n = i32;
     get_named(env, req, "width", &v); napi_get_value_int32(env, v, &i32); j->width = i32;
+    if (j->group && get_string(env, req, "gather") == "host") j->gather = SP_GROUP_GATHER_HOST;
     j->req.channel_mode = get_bool(env, req, "channelMode");
     j->req.waterfall = get_bool(env, req, "waterfall");
     j->req.block_norm = get_double(env, req, "block_norm");
@@ -347,8 +352,12 @@ void run_job(Job *j)
     r.rgba = j->rgba; r.gauge_mins = j->gmin; r.gauge_maxs = j->gmax; r.gauge_amps = j->gamp;
     r.c_hist = j->c_hist.data(); r.cb_hist = j->cb_hist.data(); r.dbfs_minmax = j->minmax;
     if (j->group) {
-        j->status = sp_group_render(j->group, &j->req, j->bytes, j->nbytes, j->width, &r);
+        j->status = sp_group_render_ex(j->group, &j->req, j->bytes, j->nbytes, j->width, &r, j->gather);
         if (j->status != SP_OK) j->error = sp_group_last_error(j->group);
+        // (read here, on the worker thread that owns the group for the duration of the job)
+        j->transport = sp_group_transport(j->group);
+        j->note = sp_group_transport_note(j->group);
+        sp_group_last_timings(j->group, &j->t_render, &j->t_gather, &j->t_download);
         return;
     }
     if (j->named) {
@@ -411,7 +420,14 @@ napi_value make_reply(napi_env env, Job *j)
         const int members = sp_group_size(j->group);
         napi_create_int32(env, members, &v); napi_set_named_property(env, out, "members", v);
         napi_create_int32(env, members > 0 ? j->width / members : 0, &v); napi_set_named_property(env, out, "sliceWidth", v);
-        napi_create_string_utf8(env, sp_group_transport(j->group), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "transport", v);
+        napi_create_string_utf8(env, j->transport.c_str(), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "transport", v);
+        napi_create_string_utf8(env, j->note.c_str(), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, out, "transportNote", v);
+        napi_value t;
+        napi_create_object(env, &t);
+        napi_create_double(env, j->t_render, &v); napi_set_named_property(env, t, "render_ms", v);
+        napi_create_double(env, j->t_gather, &v); napi_set_named_property(env, t, "gather_ms", v);
+        napi_create_double(env, j->t_download, &v); napi_set_named_property(env, t, "download_ms", v);
+        napi_set_named_property(env, out, "timings", t);
     }
     return out;
 }

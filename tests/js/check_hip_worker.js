@@ -58,7 +58,26 @@ async function main() {
             if (JSON.stringify(d.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: device-merged c_hist`)
             if (JSON.stringify(d.cB_hist) !== JSON.stringify(m.cB_hist)) failures.push(`${c.name}: device-merged cB_hist`)
             if (!G.sameF64(d.dBfs_min, e.merged.dBfs_min) || !G.sameF64(d.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: device-merged range`)
-            if (d.transport !== (c.slices === 1 ? 'none' : HipWorker.deviceCount() >= c.slices ? 'rccl' : 'peer')) failures.push(`${c.name}: transport ${d.transport}`)
+            // distinct GPUs take RCCL; an RCCL failure may only ever end in peer copies with the reason recorded
+            const distinct = c.slices > 1 && HipWorker.deviceCount() >= c.slices
+            const okTransport = c.slices === 1 ? d.transport === 'none'
+                : distinct ? (d.transport === 'rccl' || (d.transport === 'peer' && /RCCL not used/.test(d.transportNote)))
+                : d.transport === 'peer'
+            if (!okTransport) failures.push(`${c.name}: transport ${d.transport} (${d.transportNote})`)
+            if (distinct && d.transport !== 'rccl') console.error(`note: ${c.name}: ${d.transportNote}`)
+            if (!(d.timings && d.timings.render_ms > 0)) failures.push(`${c.name}: timings ${JSON.stringify(d.timings)}`)
+            // ... and with the strips meeting in host memory instead: every member writes its own band of the result
+            const h = await renderSliced({ buffer: G.makeInput(c), format: c.format, n: c.n, width: c.width, workers: c.slices, device: true,
+                gather: 'host', window: { window: windowc, weight }, cmap: G.getCmap(c, false), gain: c.gain, range: c.range,
+                channelMode: !!c.channelMode, waterfall: !!c.waterfall })
+            if (G.sha256(h.data) !== e.merged.rgba_sha256) failures.push(`${c.name}: host-gathered rgba`)
+            if (JSON.stringify(h.c_hist) !== JSON.stringify(e.merged.c_hist) || JSON.stringify(h.cB_hist) !== JSON.stringify(m.cB_hist)) failures.push(`${c.name}: host-gathered histograms`)
+            if (!G.sameF64(h.dBfs_min, e.merged.dBfs_min) || !G.sameF64(h.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: host-gathered range`)
+            if (h.transport !== 'host') failures.push(`${c.name}: transport ${h.transport} with gather: 'host'`)
+            h.replies.forEach((r, i) => {
+                for (const k of ['gauge_mins', 'gauge_maxs', 'gauge_amps'])
+                    if (Buffer.from(r[k]).toString('hex') !== e.slices[i][k]) failures.push(`${c.name}[${i}]: host-gathered ${k}`)
+            })
             d.replies.forEach((r, i) => {
                 for (const k of ['gauge_mins', 'gauge_maxs', 'gauge_amps'])
                     if (Buffer.from(r[k]).toString('hex') !== e.slices[i][k]) failures.push(`${c.name}[${i}]: device-merged ${k}`)
@@ -66,6 +85,28 @@ async function main() {
             deviceMerged++
         }
         checked++
+    }
+
+    // RCCL, as far as one GPU can execute it: with SPECTROPLOT_HIP_FORCE_RCCL a one-member group moves its own strip and record block
+    // through a grouped self ncclSend / ncclRecv on a one-rank communicator (sp_group.hip) - through addon.groupRender
+    let forcedRccl = 0
+    {
+        renderSliced.closeGroups()
+        process.env.SPECTROPLOT_HIP_FORCE_RCCL = '1'
+        for (const c of G.spec.worker_cases) {
+            const e = G.expected.find(x => x.name === c.name)
+            if (!e.merged || c.slices !== 1) continue
+            const { window: windowc, weight } = O.makeWindow(c.window, c.n)
+            const d = await renderSliced({ buffer: G.makeInput(c), format: c.format, n: c.n, width: c.width, workers: 1, device: true,
+                window: { window: windowc, weight }, cmap: G.getCmap(c, false), gain: c.gain, range: c.range,
+                channelMode: !!c.channelMode, waterfall: !!c.waterfall })
+            if (G.sha256(d.data) !== e.merged.rgba_sha256) failures.push(`${c.name}: forced-RCCL rgba`)
+            if (JSON.stringify(d.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: forced-RCCL c_hist`)
+            if (d.transport !== 'rccl') failures.push(`${c.name}: forced RCCL ran as ${d.transport} (${d.transportNote})`)
+            forcedRccl++
+        }
+        renderSliced.closeGroups()
+        delete process.env.SPECTROPLOT_HIP_FORCE_RCCL
     }
 
     // the transferable probe (lib/spectroplot.js:118-119) and other buffer-less messages produce no reply
@@ -116,7 +157,8 @@ async function main() {
     if (failures.length) { console.error(failures.slice(0, 30).join('\n')); console.error(`${failures.length} failures`); process.exit(1) }
     renderSliced.closeGroups()
     if (deviceMerged < 10) { console.error(`only ${deviceMerged} sliced cases went through the device merge`); process.exit(1) }
-    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s); ${deviceMerged} sliced cases also merged on the device (sp_group_render)`)
+    if (forcedRccl < 3) { console.error(`only ${forcedRccl} cases went through the forced RCCL self-exchange`); process.exit(1) }
+    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s); ${deviceMerged} sliced cases also merged on the device and in host memory (sp_group_render_ex), ${forcedRccl} through a forced RCCL self-exchange`)
 }
 
 // (an explicit exit: Node 12 can crash while it tears its environment down when finalizers of collected reply buffers are

@@ -125,21 +125,18 @@ def test_golden_slices_through_worker_mirror(pkg, golden):
     w.terminate()
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]], ids=lambda d: "%d_members" % len(d))
-def test_group_render_merges_on_the_device_like_the_callers_merge(pkg, golden, devices):
-    """sp_group_render: the caller's slice + merge (lib/spectroplot.js:1206-1244) from one process with the strips gathered device to
-    device and merged on the root member, against the merged vectors of the real reference for the same worker count.  One member needs
-    no transport; several members on this box's one GPU take the peer-copy path (RCCL's needs distinct devices)."""
-    g = pkg.Group(devices)
+def _check_group_against_merged_vectors(pkg, golden, g, members, gather, expect_transport):
     ran = 0
     for c in golden.spec["worker_cases"]:
         e = golden.expected[c["name"]]
-        if "merged" not in e or c["slices"] != len(devices):
+        if "merged" not in e or c["slices"] != members:
             continue
         data = golden.input(c)
         win, weight = pyoracle.window(c["window"], c["n"])
         lut = golden.lut(c, force_ends=c["force_ends"])
-        m = g.render(c["format"], data, c["n"], win, 1.0 / weight, c["gain"], c["range"], lut, c["width"], c["channelMode"], c["waterfall"])
+        # (the caller's buffers arrive dirty: what no slice draws must come back cleared, as on the caller's fresh canvas)
+        m = g.render(c["format"], data, c["n"], win, 1.0 / weight, c["gain"], c["range"], lut, c["width"], c["channelMode"], c["waterfall"],
+                     gather=gather, dirty=0xAB)
         assert goldenlib.sha256(m["rgba"]) == e["merged"]["rgba_sha256"], c["name"]
         assert [int(v) for v in m["c_hist"]] == e["merged"]["c_hist"], c["name"]
         assert goldenlib.same_f64(m["dBfs_min"], e["merged"]["dBfs_min"]) and goldenlib.same_f64(m["dBfs_max"], e["merged"]["dBfs_max"]), c["name"]
@@ -153,11 +150,81 @@ def test_group_render_merges_on_the_device_like_the_callers_merge(pkg, golden, d
                 cb[int(b)] += v
         assert np.array_equal(m["cB_hist"].astype(np.int64), cb), c["name"]
         for k in ("gauge_mins", "gauge_maxs", "gauge_amps"):
-            assert not m[k][len(devices) * sw:].any(), (c["name"], k)
-        assert g.transport() == ("none" if len(devices) == 1 else "peer")
+            assert not m[k][members * sw:].any(), (c["name"], k)
+        assert g.transport() == expect_transport, (g.transport(), g.transport_note())
+        t = g.timings()
+        assert t[0] > 0 and all(v >= 0 for v in t), t
+        image_bytes, staging_bytes = g.root_bytes()
+        if gather == "device" and expect_transport in ("none", "peer"):
+            # copies land in the image itself: the root holds the image and nothing beside it
+            assert staging_bytes == 0 and image_bytes >= m["rgba"].size, (image_bytes, staging_bytes)
         ran += 1
+    assert ran >= 1, "no golden case with %d slices" % members
+
+
+@pytest.mark.parametrize("gather", ["device", "host"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0]], ids=lambda d: "%d_members" % len(d))
+def test_group_render_merges_on_the_device_like_the_callers_merge(pkg, golden, devices, gather):
+    """sp_group_render_ex: the caller's slice + merge (lib/spectroplot.js:1206-1244) from one process, against the merged vectors of the
+    real reference for the same worker count, both layouts, widths that leave columns un-rendered.  gather = device: strips meet in the
+    root member's HBM (one member needs no transport; several members on this box's one GPU take peer copies, straight into their bands
+    of the image).  gather = host: every member writes its band of the host image itself and the side outputs are merged on the host."""
+    g = pkg.Group(devices)
+    _check_group_against_merged_vectors(pkg, golden, g, len(devices), gather,
+                                        "host" if gather == "host" else "none" if len(devices) == 1 else "peer")
     g.close()
-    assert ran >= 1, "no golden case with %d slices" % len(devices)
+
+
+def test_group_forced_rccl_moves_the_roots_strip_through_a_self_exchange(pkg, golden, monkeypatch):
+    """SPECTROPLOT_HIP_FORCE_RCCL=1: what one GPU can execute of north_star's transport.  A one-member group loads librccl,
+    makes a one-rank communicator (ncclCommInitAll) and moves its own strip and record block through a grouped ncclSend / ncclRecv to
+    itself - the dlopen table, the signatures, ncclUint8, the group call and the stream ordering of the multi-GPU gather - instead of
+    two device copies; both layouts (the waterfall's receive lands in the image, the spectrogram's beside it)."""
+    monkeypatch.setenv("SPECTROPLOT_HIP_FORCE_RCCL", "1")
+    g = pkg.Group([0])
+    _check_group_against_merged_vectors(pkg, golden, g, 1, "device", "rccl")
+    assert g.transport_note() == "", g.transport_note()
+    image_bytes, staging_bytes = g.root_bytes()
+    assert staging_bytes > 0          # the spectrogram layout's strip arrived beside the image
+    g.close()
+
+
+def test_group_rccl_failures_end_in_peer_copies_with_a_note(pkg, golden, monkeypatch):
+    """No RCCL failure may fail a render or be retried on every render.  (a) A library that cannot be loaded (bogus name through
+    SPECTROPLOT_HIP_RCCL_LIB); (b) a real librccl whose ncclCommInitAll refuses the member list (two members on one device: 'duplicate
+    GPU').  Both: results from peer copies, bit-exact against the merged vectors, the reason in transport_note(), and the second
+    render does not try again (the note stays one entry long)."""
+    monkeypatch.setenv("SPECTROPLOT_HIP_FORCE_RCCL", "1")
+    monkeypatch.setenv("SPECTROPLOT_HIP_RCCL_LIB", "/nonexistent/librccl_bogus.so")
+    g = pkg.Group([0, 0])
+    _check_group_against_merged_vectors(pkg, golden, g, 2, "device", "peer")
+    note = g.transport_note()
+    assert "RCCL not used" in note and "librccl_bogus" in note and note.count("RCCL not used") == 1, note
+    g.close()
+    monkeypatch.delenv("SPECTROPLOT_HIP_RCCL_LIB")
+    g = pkg.Group([0, 0])
+    _check_group_against_merged_vectors(pkg, golden, g, 2, "device", "peer")
+    note = g.transport_note()
+    assert "ncclCommInitAll" in note and note.count("RCCL not used") == 1, note
+    g.close()
+
+
+def test_group_render_rejects_what_it_cannot_read(pkg):
+    """A request with a null taper / colour map is an invalid argument, not a crash - also once a plan is cached."""
+    import ctypes as C
+    L = pkg.Library.get().L
+    g = pkg.Group([0])
+    win, weight = pyoracle.window("hann", 64)
+    lut = np.zeros((4, 3), np.uint8)
+    data = np.zeros(2 * 64 * 8, np.uint8)
+    g.render("CU8", data, 64, win, 1.0 / weight, 6.0, 30.0, lut, 8)
+    _Request, _Reply = pkg.binding._Request, pkg.binding._Reply
+    req = _Request(2, 64, 0, 0, 4, 0, 1.0 / weight, 6.0, 30.0, None, None)
+    rep = _Reply(None, None, None, None, None, None, None)
+    for mode in (0, 1):
+        assert L.sp_group_render_ex(g.h, C.byref(req), data.ctypes.data_as(C.c_void_p), data.size, 8, C.byref(rep), mode) == -1
+    assert L.sp_group_render_ex(g.h, C.byref(req), data.ctypes.data_as(C.c_void_p), data.size, 8, C.byref(rep), 7) == -1
+    g.close()
 
 
 SEEDED = [
