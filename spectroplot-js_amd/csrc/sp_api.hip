@@ -710,7 +710,7 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     a.bytes = (const uint8_t *)d_bytes;
     a.nbytes = (int64_t)nbytes;
     a.nelem = (int64_t)(nbytes / (size_t)f.elem);
-    a.stride = stride;
+    a.stride = width > 1 ? stride : 0.0;   // one frame: (S - n) / 0 is an infinity or a NaN and ~~(0.5 + it * 0) = 0, as with 0
     a.n = n;
     a.levels = plan->levels;
     a.width = width;

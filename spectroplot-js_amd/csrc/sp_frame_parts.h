@@ -276,15 +276,27 @@ __device__ inline void load_frame(const FrameArgs &a, const spfmt::View &view, i
 // at n <= 1024 (twiddles and tables are in LDS), so nothing forces an early wait on them.
 // 3-byte samples are fetched as one unaligned dword; `back` (0 or 1) moves the load one byte down for a frame that ends with the
 // buffer, whose last dword would otherwise reach one byte past it (the decode shifts such words right by 8).
-template <int BYTES>
+// UNIFORM: the frame is wave-uniform (T >= 64) and `start` has been made so (readfirstlane): the frame's base address is SALU work
+// and every load is SGPR base + one loop-invariant 32-bit lane offset + an immediate - no address arithmetic in the VALU and no
+// per-register base pointers (the compiler's own choice, sixteen uniform bases `base + rev4(e)*T*BYTES`, cost 14 spilled SGPRs and as
+// many v_readlane per frame at n = 1024).  Below a wave per frame the addresses are left to the compiler as before.
+template <int BYTES, bool UNIFORM = false>
 __device__ inline void issue_raw(const uint8_t *__restrict__ base, int64_t start, int T, int sidx, uint32_t (&lo)[16],
                                  uint32_t (&hi)[BYTES == 8 ? 16 : 1], int back = 0)
 {
+    const uint8_t *fb;     // the frame's first byte (minus `back`), or the lane's first sample
+    size_t lane_off = 0;
+    if constexpr (UNIFORM) {
+        fb = base + start * BYTES - back;
+        lane_off = (size_t)(unsigned)(sidx * BYTES);
+    } else {
+        fb = base - back;
+    }
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const uint8_t *p = base + (start + rev4(e) * T + sidx) * BYTES;
+        const uint8_t *p = UNIFORM ? fb + lane_off + (size_t)(rev4(e) * T * BYTES) : fb + (start + rev4(e) * T + sidx) * BYTES;
         if constexpr (BYTES == 3) {
-            lo[e] = *(const uint32_t *)(p - back);
+            lo[e] = *(const uint32_t *)p;
         } else if constexpr (BYTES == 1) {
             lo[e] = *p;
         } else if constexpr (BYTES == 2) {

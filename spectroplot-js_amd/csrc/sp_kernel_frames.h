@@ -110,23 +110,28 @@ __host__ __device__ inline int group_frames_for(int n, int want)
 // set of frame-extreme slots (n >= 2048 has no LDS left for one: they are evaluated behind the first barrier there)
 __host__ __device__ inline constexpr bool late_side_outputs(int n) { return n <= 1024; }
 
+// The RGBA LUT and the merged histogram cells sit at FIXED LDS addresses in front of everything whose size depends on the request, so
+// that a pixel's LUT read and its histogram atomic are `ds_* vaddr offset:imm` with vaddr = index * 4 alone: one VALU instruction per
+// pixel for either address (v_lshlrev_b32_sdwa of a tile byte; v_add_lshl_u32 of colour index + level) instead of two.
+constexpr int kOffLut = 0;                                        // u32[kLdsMaxLut]
+constexpr int kOffCells = kOffLut + kLdsMaxLut * 4;               // u32[kMaxCells]: word c counts the pixels with colour index + level == c
+constexpr int kOffXch = (kOffCells + kMaxCells * 4 + 15) & ~15;   // exchange buffers, then the rest of Layout
+
 struct Layout {
-    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_lut, off_cells, off_done, off_amp, off_win, total;
+    int off_tw, off_gedge, off_cbedge, off_mm, off_tile, off_done, off_amp, off_win, total;
 };
 
 __host__ __device__ inline Layout layout(int n, int lut_len, int group_frames)
 {
     Layout l;
     const int fpb = kFrameThreads * 16 / n;
-    int o = fpb * (n + n / 16) * 8;                              // exchange buffers
+    int o = kOffXch + fpb * (n + n / 16) * 8;                    // exchange buffers
     l.off_tw = o;     o += frames_tw_entries(n) * 16;
     l.off_gedge = o;  o += lut_len * 8;                          // exact edge tables (read by the few lanes the f32 test sends there)
     l.off_cbedge = o; o += (SP_CB_HIST_SIZE + 1) * 8;
     o = (o + 15) & ~15;
     l.off_mm = o;     o += (late_side_outputs(n) ? 2 : 1) * group_frames * mm_slots(n) * 2 * 8;   // frame extremes (n <= 1024: by group parity)
     l.off_tile = o;   o += (group_frames * (n + kTilePad) + 15) & ~15;
-    l.off_lut = o;    o += lut_len * 4;
-    l.off_cells = o;  o += (lut_len + SP_CB_HIST_SIZE + 2) * 4;
     l.off_done = o;   o += 32;                                   // arrival counters: the two wave sets (last write-out), the frames' waves; [7]: "last workgroup"
     o = (o + 15) & ~15;
     l.off_amp = o;    o += 16 + 2 * group_frames * 16;           // the workgroup's extreme |X|^2 so far; raw centre samples of two groups' frames
@@ -185,6 +190,32 @@ __device__ inline void store_nt(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c
     __builtin_nontemporal_store(v, (u32x4 *)dst);
 }
 
+// LDS accesses at a compile-time offset plus a byte offset held in a VGPR, through a pointer made from the integer (the dynamic LDS
+// block starts at address 0: k_frames has no static LDS and checks it once): `ds_* vaddr offset:imm`.  Going through `smem + ...`
+// instead leaves a `v_add_u32 v, 0, v` per access behind - the block's address is only replaced by its value after the last folding pass.
+typedef __attribute__((address_space(3))) uint32_t *LdsU32;
+__device__ inline uint32_t lds_read_u32(int fixed_off, unsigned var_off) { return *(LdsU32)(uintptr_t)(unsigned)(fixed_off + var_off); }
+__device__ inline void lds_count(int fixed_off, unsigned var_off)
+{
+    __hip_atomic_fetch_add((LdsU32)(uintptr_t)(unsigned)(fixed_off + var_off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 4 * byte J of a dword in ONE instruction (sub-dword addressing): the LDS byte offset of a tile byte's LUT entry.
+template <int J>
+__device__ inline unsigned byte_times4(unsigned w)
+{
+    unsigned r;
+    if constexpr (J == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w));
+    else if constexpr (J == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w));
+    else if constexpr (J == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w));
+    return r;
+}
+
+// Does any of the raw f32 words (lo[e], hi[e]: the two halves of one 64-bit load) hold an infinity or a NaN?  x*0 is NaN exactly for
+// those; v_pk_fma_f32 takes a sample's two words at once.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // The launch arguments as they lie in the kernel-argument segment (FrameArgs is k_frames' first parameter), behind an opaque copy of
 // the segment pointer: fields read through it are fetched (s_load) where they are used - the side outputs once per group, the
 // request's end - instead of sitting in SGPRs from the kernel's first instruction on (the compiler loads every field of a by-value
@@ -233,17 +264,19 @@ __device__ inline void fft_pass1(double (&re)[16], double (&im)[16])
     }
 }
 
-// Does any of the raw f32 words of this wave's frames hold an infinity or a NaN?  x*0 is NaN exactly for those.
 template <int NHI>
 __device__ inline bool raw_f32_nonfinite(const uint32_t (&lo)[16], const uint32_t (&hi)[NHI])
 {
-    float s = 0.0f;
+    static_assert(NHI == 16, "8-byte samples: two f32 words each");
+    unsigned long long s = 0ull;
+    const unsigned long long zero = 0ull;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        s = fmaf(__uint_as_float(lo[e]), 0.0f, s);
-        s = fmaf(__uint_as_float(hi[NHI == 16 ? e : 0]), 0.0f, s);
+        const unsigned long long w = ((unsigned long long)hi[e] << 32) | lo[e];   // the register pair the 64-bit load filled
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(s) : "v"(w), "v"(zero));
     }
-    return __ballot(s != s) != 0ull;
+    const float s0 = __uint_as_float((uint32_t)s), s1 = __uint_as_float((uint32_t)(s >> 32));
+    return __ballot(s0 != s0 || s1 != s1) != 0ull;
 }
 
 
@@ -327,18 +360,20 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Layout lay = layout(N, a.lut_len, group_frames);
-    double *s_xch = (double *)smem;
+    double *s_xch = (double *)(smem + kOffXch);
     double2 *s_tw = (double2 *)(smem + lay.off_tw);
     const double *edge_g = (const double *)(smem + lay.off_gedge);
     const double *edge_cb = (const double *)(smem + lay.off_cbedge);
     unsigned long long *s_mm = (unsigned long long *)(smem + lay.off_mm);
     unsigned char *s_tile = smem + lay.off_tile;
-    unsigned int *s_lut = (unsigned int *)(smem + lay.off_lut);
-    unsigned int *s_cells = (unsigned int *)(smem + lay.off_cells);      // word c counts the pixels with colour index + level == c
+    unsigned int *const s_lut = (unsigned int *)(smem + kOffLut);
+    unsigned int *const s_cells = (unsigned int *)(smem + kOffCells);
     [[maybe_unused]] unsigned int *s_done = (unsigned int *)(smem + lay.off_done);
     double *s_red = (double *)(smem + lay.off_amp);                           // the workgroup's share of dBfs_min / dBfs_max so far
     double2 *s_amp = (double2 *)(smem + lay.off_amp + 16);                    // [2][group_frames] (I, Q) of sample n/2, by group parity
 
+    // (lds_read_u32 / lds_count address the dynamic LDS block from 0)
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const int tid = threadIdx.x;
     [[maybe_unused]] const int lane = tid & 63;
     const int fs = tid / T;                         // frame slot within a round
@@ -363,10 +398,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     int raw_back = 0;
     auto request = [&](int xq) {
         if constexpr (PF) {
+            // (the prefetching variants only run when every frame lies inside the buffer: launch_frames)
             const int xc = xq < a.x_end ? xq : a.x_end - 1;
-            const int64_t st = frame_start(a.stride, xc);
+            constexpr bool UNI = T >= 64;   // a frame per wave or more: its start is wave-uniform
+            const int sv = frame_start_in_bounds(a.stride, xc);
+            const int64_t st = UNI ? __builtin_amdgcn_readfirstlane(sv) : sv;
             if constexpr (PFB == 3) raw_back = (st + N) * 3 + 1 > a.nbytes ? 1 : 0;
-            issue_raw<PFB>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
+            issue_raw<PFB, UNI>(a.bytes, st, T, sidx_pf, raw_lo, raw_hi, raw_back);
         }
     };
     // n = 1024, 32-frame groups: the first / second waves of the SIMDs each take one half of a group's frames
@@ -476,6 +514,11 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     const float g_a = a.g2_a, g_b = a.g2_b, g_m = a.g2_m;
     const float c_a = a.c2_a, c_b = a.c2_b, c_m = a.c2_m, c_lo = a.c2_lo, c_hi = a.c2_hi;
     const float thr = fminf(a.g2_thr, a.c2_thr);
+    // A VALU instruction reads ONE scalar register: with both coefficients of a scale in SGPRs the compiler copies one of them into a
+    // VGPR again for every batch of bins (24 v_mov per frame).  The addends and the upper clamp bound live in VGPRs instead.
+    // (n <= 1024, where registers are left: above, the loop sits at the 256-VGPR limit and three more spill)
+    float g_a_v = g_a, c_a_v = c_a, c_hi_v = c_hi;
+    if constexpr (LOG2N <= 10 && !CH && !(PFB == 8 && LOG2N < 9)) asm volatile("" : "+v"(g_a_v), "+v"(c_a_v), "+v"(c_hi_v));
     // clamp bounds of the colour value: clipped pixels sit in the middle of the first / last step, far from the risky zone
     const float g_lo = 0.5f, g_hi = (float)cmax + 0.5f;
     const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
@@ -539,7 +582,8 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                 // one of a thread's four dwords (bins tl + (4*e4 + j)*T, j = 0..3) of 4 consecutive frames: four 16-byte stores in four
                 // rows; the items of a row segment (8 frame quads) sit in lanes 4 apart, and a wave's dword reads are conflict-free
                 // (tile pitch = 1 dword mod 8).
-                const int quads = fcount / 4;
+                const int quads = fcount / 4;                     // a power of two (launch_frames)
+                const int lq = 31 - __builtin_clz((unsigned)quads);
                 const int items = (N / 4) * quads;
                 for (int it0 = dt + part * 2 * dthreads; it0 < items; it0 += nparts * 2 * dthreads) {
                     uint32_t gb[2][4];
@@ -548,19 +592,24 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     for (int u = 0; u < 2; u++) {
                         const int it = it0 + u * dthreads;
                         const int itc = it < items ? it : it0;
-                        const int e4 = itc & 3, fq = (itc >> 2) % quads, tq = (itc >> 2) / quads;   // tq: thread of the frame
+                        const int e4 = itc & 3, fq = (itc >> 2) & (quads - 1), tq = (itc >> 2) >> lq;   // tq: thread of the frame
                         i0v[u] = tq + 4 * e4 * T;
                         xav[u] = it < items ? x0 + f0 + fq * 4 : a.x_end;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) gb[u][k] = *(const uint32_t *)(s_tile + (f0 + fq * 4 + k) * tile_pitch + tq * 16 + e4 * 4);
+                        for (int k = 0; k < 4; k++)
+                            gb[u][k] = *(const uint32_t *)(s_tile + __umul24((unsigned)(f0 + fq * 4), (unsigned)tile_pitch) + k * tile_pitch + tq * 16 + e4 * 4);
                     }
                     uint32_t px[2][4][4];
+                    const auto lut_at = [&](unsigned off4) { return lds_read_u32(kOffLut, off4); };
 #pragma unroll
                     for (int u = 0; u < 2; u++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-#pragma unroll
-                            for (int k = 0; k < 4; k++) px[u][j][k] = s_lut[(gb[u][k] >> (8 * j)) & 0xff];
+                        for (int k = 0; k < 4; k++) {
+                            px[u][0][k] = lut_at(byte_times4<0>(gb[u][k]));
+                            px[u][1][k] = lut_at(byte_times4<1>(gb[u][k]));
+                            px[u][2][k] = lut_at(byte_times4<2>(gb[u][k]));
+                            px[u][3][k] = lut_at(byte_times4<3>(gb[u][k]));
+                        }
                     if (img_fast) {
                         // rows are 16-byte aligned, the width is a multiple of 4 and the image is below 4 GiB: 32-bit offsets from the
                         // uniform base (24-bit multiplies), no per-store checks
@@ -619,9 +668,11 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     const int c0 = (tq + 4 * e4 * T + N / 2 - 1) & (N - 1);
                     uint32_t *const row = (uint32_t *)(img + (size_t)(img_width - 1 - xa) * N * 4);
                     uint32_t *const p = row + (c0 == N - 1 ? -1 : c0);
-                    __builtin_nontemporal_store(s_lut[gb & 0xff], row + c0);
-#pragma unroll
-                    for (int j = 1; j < 4; j++) __builtin_nontemporal_store(s_lut[(gb >> (8 * j)) & 0xff], p + j * T);
+                    const auto lut_at = [&](unsigned off4) { return lds_read_u32(kOffLut, off4); };
+                    __builtin_nontemporal_store(lut_at(byte_times4<0>(gb)), row + c0);
+                    __builtin_nontemporal_store(lut_at(byte_times4<1>(gb)), p + 1 * T);
+                    __builtin_nontemporal_store(lut_at(byte_times4<2>(gb)), p + 2 * T);
+                    __builtin_nontemporal_store(lut_at(byte_times4<3>(gb)), p + 3 * T);
                 }
             }
         }
@@ -849,6 +900,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     double abs2[EB];
                     float tg[EB], tc[EB];
                     int gi[EB], cell[EB];
+                    unsigned cell4[EB];              // 4 * (colour index + level): the byte offset of the pixel's merged cell
                     bool risky[EB];
                     float worst = 0.0f;   // largest fractional part of the batch, either scale
                     // written stage by stage: the four chains are independent, and every step of a chain waits on the one before
@@ -866,13 +918,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
-                        tg[k] = fmaf(g_b, l2[k], g_a);
-                        tc[k] = fmaf(c_b, l2[k], c_a);
+                        tg[k] = fmaf(g_b, l2[k], g_a_v);
+                        tc[k] = fmaf(c_b, l2[k], c_a_v);
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
                         tg[k] = __builtin_amdgcn_fmed3f(tg[k], g_lo, g_hi);
-                        tc[k] = __builtin_amdgcn_fmed3f(tc[k], c_lo, c_hi);
+                        tc[k] = __builtin_amdgcn_fmed3f(tc[k], c_lo, c_hi_v);
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
@@ -884,7 +936,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         // (the clamps have turned a NaN into a bound, so the fractional parts are numbers; one threshold, the
                         // smaller of the two, serves both scales)
                         worst = fmaxf(fmaxf(worst, __builtin_amdgcn_fractf(tg[k])), __builtin_amdgcn_fractf(tc[k]));   // one v_max3_f32
-                        cell[k] += gi[k];
+                        cell4[k] = (unsigned)(cell[k] + gi[k]) << 2;                   // one v_add_lshl_u32
                     }
                     if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
 #pragma unroll
@@ -913,7 +965,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                                 c = cell_sp0 + 1;
                             }
                             gi[k] = risky[k] ? g : gi[k];
-                            cell[k] = risky[k] ? c : cell[k];
+                            cell4[k] = risky[k] ? (unsigned)c << 2 : cell4[k];
                         }
                     }
 #pragma unroll
@@ -924,7 +976,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
-                        atomicAdd(&s_cells[cell[k]], 1u);
+                        lds_count(kOffCells, cell4[k]);
                     }
                 }
                 const double mn = min_raw(min_raw(mn4[0], mn4[1]), min_raw(mn4[2], mn4[3]));
@@ -987,7 +1039,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         // LDS).  The exchange buffers are idle by now and hold the prefix.  (Counts of one workgroup fit 32 bits, as s_cells does.)
         constexpr int kPer = 3;
         static_assert(kThreads * kPer >= kMaxCells, "every cell needs a thread");
-        unsigned int *const s_pre = (unsigned int *)smem;                     // [kThreads * kPer + 1]: s_pre[c] = sum of the cells [0, c)
+        unsigned int *const s_pre = (unsigned int *)(smem + kOffXch);         // [kThreads * kPer + 1]: s_pre[c] = sum of the cells [0, c)
         unsigned int *const s_part = s_pre + kThreads * kPer + 4;             // [kThreads / 64] wave totals
         unsigned int v[kPer], run = 0;
 #pragma unroll
@@ -1099,6 +1151,7 @@ inline int launch_frames(const FrameArgs &a, int format, const double2 *stage_tw
     int want = 32;
     while (want > 4 && (a.x_end - a.frame0 + want - 1) / want < 2 * cu_count) want >>= 1;
     const int gf = group_frames_for(n, want);
+    if (gf & (gf - 1)) return SP_ERR_UNSUPPORTED;   // (the write-out splits item numbers with shifts; every n in range gives a power of two)
     const int groups = (a.x_end - a.frame0 + gf - 1) / gf;
     const Layout lay = layout(n, a.lut_len, gf);
     if (lay.total > 160 * 1024) return SP_ERR_UNSUPPORTED;

@@ -63,6 +63,11 @@ __device__ inline double d_of_abs2(double abs2, double block_norm_db, double gai
 // frame start: ~~(0.5 + stride * x)                                                          worker.js:72
 __host__ __device__ inline int32_t frame_start(double stride, int32_t x) { return spjs::to_int32(0.5 + stride * (double)x); }
 
+// The same for launches whose frames all lie inside the buffer (sp_api.hip: in_bounds requires 0 <= 0.5 + stride * x < 2^31 - 1 for every
+// frame, and passes stride = 0 for a one-frame image): ToInt32 is then plain truncation - one v_cvt_i32_f64 instead of the ~18
+// instructions and two branches of the general conversion.
+__device__ inline int32_t frame_start_in_bounds(double stride, int32_t x) { return (int32_t)(0.5 + stride * (double)x); }
+
 // Exact colour index from the edge table: number of edges 1..lut_len-1 that are <= abs2 (NaN -> 0).
 __device__ inline int32_t gray_exact(const double *edge, int32_t lut_len, double abs2)
 {
