@@ -155,6 +155,14 @@ int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size
  */
 int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
                     int32_t image_width);
+/*
+ * Bytes of samples the last sp_render / sp_render_strip / sp_render_named on this context sent over the host link.  A request whose
+ * frames are more than n samples apart (stride > n, lib/worker.js:50: the reference's loop skips the samples in between, :70-75) and lie
+ * inside the capture uploads the frames' own samples only, as rows of pitched copies into a packed device buffer; every other request
+ * uploads the capture as it is.  SPECTROPLOT_HIP_NO_PACKED_UPLOAD=1 turns the packed upload off; SPECTROPLOT_HIP_RENDER_CHUNKS=2..16
+ * overrides how many chunks of frames a large request is pipelined in (default 4, 8 or 16 by size).
+ */
+int sp_context_last_upload_bytes(const sp_context *ctx, size_t *nbytes);
 
 /*
  * The same with the request given by names, as the reference's caller assembles its message from options

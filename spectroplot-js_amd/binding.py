@@ -126,6 +126,7 @@ class Library:
             L.sp_group_last_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
             L.sp_group_root_bytes.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
             L.sp_render_strip.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply), i32]
+            L.sp_context_last_upload_bytes.argtypes = [vp, C.POINTER(sz)]
         L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
 
     @classmethod
@@ -232,6 +233,12 @@ class Context:
 
     def synchronize(self):
         self._chk(self.lib.L.sp_context_synchronize(self.h))
+
+    def last_upload_bytes(self):
+        """Bytes of samples the last render() sent over the host link (a sparse request - stride > n - sends its frames only)."""
+        v = C.c_size_t()
+        self._chk(self.lib.L.sp_context_last_upload_bytes(self.h, C.byref(v)))
+        return v.value
 
     def enable_timing(self, on=True):
         self._chk(self.lib.L.sp_context_enable_timing(self.h, int(on)))

@@ -87,7 +87,7 @@ struct sp_context {
     HostBuffer host_small;
     // sp_render's copy streams and events: the image goes back to the host chunk by chunk while later chunks still arrive
     hipStream_t copy_in = nullptr, copy_out = nullptr;
-    static constexpr int kMaxChunks = 8;
+    static constexpr int kMaxChunks = 16;
     hipEvent_t ev_arrived[kMaxChunks] = {}, ev_rendered[kMaxChunks] = {};
     sp_plan *cached_plan = nullptr;
     // sp_render_named: the names and numbers the cached plan was built from (empty: the cached plan came from arrays)
@@ -99,6 +99,7 @@ struct sp_context {
     double named_block_norm = 0;
     long long plans_created = 0; // sp_context_plan_creations: how many plans (table sets on the device) this context has built
     bool acc_dirty = false;      // a request failed between its launches: accumulators must be re-initialised
+    size_t last_upload_bytes = 0; // what the last sp_render sent over the host link (a sparse request sends its frames only)
     uint32_t seq = 0;            // requests started on this context (k_frames publishes the number once the reply is cleared; never 0)
     // timing
     bool timing = false;
@@ -637,8 +638,17 @@ extern "C" const char *sp_plan_kernel_name(const sp_plan *plan)
 // `last` ends the request: k_frames then produces histograms and dBfs range itself (its last workgroup; the gauges it writes group by
 // group in every launch), behind the scratch kernel a finish kernel is queued.  sp_plan_execute is the whole range in one launch - ONE
 // kernel for every request k_frames covers; sp_render walks the image in chunks so that the copies to and from the host overlap.
+// `src` (sp_render's packed upload, below): the frames [x_begin, x_end) do not lie in the capture at d_bytes but in a packed copy of it;
+// the kernel is handed that copy's address, length and stride instead (every frame inside it), everything else - image geometry, frame
+// numbers, reply - stays the request's.
+struct PackedSource {
+    const void *bytes;     // address of (virtual) sample 0 of the packed layout
+    size_t nbytes;         // its (virtual) length
+    double stride;         // frame x starts at sample ~~(0.5 + stride * x) of it
+};
+
 static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, int32_t x_begin, int32_t x_end, bool first,
-                              bool last, const sp_reply *out)
+                              bool last, const sp_reply *out, const PackedSource *src = nullptr)
 {
     if (!plan || !out) return SP_ERR_INVALID_ARG;
     sp_context *ctx = plan->ctx;
@@ -669,10 +679,15 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         return SP_OK;
     }
 
-    const double stride = (sample_count - (double)n) / (double)(width - 1);        // worker.js:50
+    double stride = (sample_count - (double)n) / (double)(width - 1);              // worker.js:50
     // do all frames lie inside the buffer?
     bool in_bounds = false;
-    {
+    if (src) {
+        d_bytes = src->bytes;
+        nbytes = src->nbytes;
+        stride = src->stride;
+        in_bounds = true;
+    } else {
         const double last_d = 0.5 + stride * (double)(width - 1);
         if (width == 1) {
             in_bounds = (size_t)n * (size_t)f.width <= nbytes;
@@ -683,6 +698,7 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
     }
 
     const int which = plan_kernel(plan);
+    if (src && which != 3) return fail(ctx, SP_ERR_INVALID_ARG, "a packed source is for the frame-loop kernel only");
     int rc = which == 3 ? SP_OK : ctx->frame_minmax.reserve(2 * (size_t)width * sizeof(double));
     if (rc) return fail(ctx, rc, "workspace: out of device memory");
     int finish_blocks = 3 * ((width + spk::kFinishThreads - 1) / spk::kFinishThreads);   // three roles per 256 frames
@@ -932,6 +948,134 @@ static bool same_request(const sp_plan *p, const sp_request *r)
     return memcmp(p->lut.data(), r->lut_rgb, 3 * (size_t)r->lut_len) == 0;
 }
 
+// ---- sparse requests: upload only what the frames read --------------------------------------------------------------------------------
+// With stride > n the reference's loop touches n samples per frame and skips the rest (lib/worker.js:50, 70-75) - its interactive shape:
+// a long capture at a screen-wide `width`.  Copying the capture contiguously moves stride / n times the bytes any frame reads.  Instead
+// a chunk's frames travel as the rows of pitched copies (hipMemcpy2DAsync: source rows floor(stride) samples apart) into a packed device
+// buffer whose rows are P samples apart, and the kernel is launched on that buffer with the stride P + frac(stride): frame x then
+// starts at ~~(0.5 + (P + frac) x) = P x + floor(0.5 + frac x), which is where the pitched copy put it, because the capture has it at
+// floor(stride) x + floor(0.5 + frac x).  The identity holds in exact arithmetic; the two sides round differently in f64, so the host
+// evaluates both for EVERY frame and takes the contiguous path if a single one disagrees.  The start's fractional drift within a chunk
+// (d_j = start_j - start_0 - j floor(stride), 0 <= d_j <= j) is what a pitched copy cannot follow row by row: it covers a run of rows
+// whose drifts differ by at most `span` samples and brings that many samples more per row (span: a few hundred samples, at most n/2,
+// chosen below to balance the cost of a copy call against the extra bytes); P = n + the widest run's range.
+// A frame's centre sample (gauge_amps) lies inside the frame, and nothing else of the path depends on where a frame came from.
+struct PackedBlock {
+    int32_t j0, j1;        // rows of the chunk (frame x0 + j)
+    int32_t dmin, dmax;    // their drifts lie in [dmin, dmax]
+};
+struct PackedChunk {
+    int32_t x0 = 0, x1 = 0;
+    int64_t first = 0;     // the capture's sample where frame x0 starts
+    int64_t F = 0;         // samples between the capture's rows: floor(stride)
+    int64_t P = 0;         // samples between the device rows
+    size_t dev_off = 0;    // the chunk's byte offset in the staging buffer
+    double stride2 = 0;    // P + frac(stride): the kernel's stride
+    int64_t pos2_x0 = 0;   // ~~(0.5 + stride2 * x0): the kernel's start of frame x0
+    int64_t pos2_last = 0; // ... and of frame x1 - 1
+    std::vector<PackedBlock> blocks;
+    std::vector<int32_t> drift;   // d_j per row
+};
+
+// Cuts [0, width) at `bounds` and lays every chunk out; false = this request is not worth packing or cannot be (then nothing is used).
+static bool build_packed_chunks(int n, int sample_width, size_t nbytes, int32_t width, double stride, const std::vector<int32_t> &bounds,
+                                std::vector<PackedChunk> &out, size_t *dev_bytes, size_t *link_bytes)
+{
+    out.clear();
+    if (width < 2 || !(stride > (double)n) || !std::isfinite(stride) || !(0.5 + stride * (double)(width - 1) < 2147483000.0)) return false;
+    const int64_t F = (int64_t)std::floor(stride);
+    const double frac = stride - (double)F;
+    size_t off = 256, moved = 0;
+    for (size_t c = 0; c + 1 < bounds.size(); c++) {
+        PackedChunk ch;
+        ch.x0 = bounds[c];
+        ch.x1 = bounds[c + 1];
+        if (ch.x1 <= ch.x0) continue;
+        ch.first = spjs::to_int32(0.5 + stride * (double)ch.x0);                       // worker.js:72
+        ch.F = F;
+        const int rows = ch.x1 - ch.x0;
+        ch.drift.resize((size_t)rows);
+        for (int j = 0; j < rows; j++) {
+            const int64_t d = (int64_t)spjs::to_int32(0.5 + stride * (double)(ch.x0 + j)) - ch.first - (int64_t)j * F;
+            if (d < 0 || d > (int64_t)rows) return false;       // (0 <= d_j <= j in exact arithmetic)
+            ch.drift[(size_t)j] = (int32_t)d;
+        }
+        // the frame must also END inside the capture (the caller established in_bounds for the request as a whole)
+        if ((size_t)(ch.first + (int64_t)(rows - 1) * F + ch.drift[(size_t)rows - 1] + n) * (size_t)sample_width > nbytes) return false;
+        // runs of rows whose drifts stay within `span` samples of each other: one pitched copy each, its rows widened by the run's drift
+        // range.  A copy call costs the link ~11 us (tools/pcie_probe.hip: 17 MiB in 16 pitched copies 0.49 ms, in one 0.32 ms), a
+        // widened row span / 2 samples on average: rows * frac / span calls against rows * span / 2 samples at ~55 GB/s balance at
+        // span = sqrt(2 * 11 us * frac * 55 GB/s / bytes per sample) - 275 samples for cf32 at frac = 0.5 - kept within [16, n/2].
+        int32_t span = (int32_t)std::sqrt(2.0 * 11e-6 * (frac > 1e-3 ? frac : 1e-3) * 55e9 / (double)sample_width);
+        span = span > n / 2 ? n / 2 : span;
+        span = span < 16 ? 16 : span;
+        int32_t widest = 0;
+        for (int j = 0; j < rows;) {
+            PackedBlock b{j, j + 1, ch.drift[(size_t)j], ch.drift[(size_t)j]};
+            while (b.j1 < rows) {
+                const int32_t d = ch.drift[(size_t)b.j1];
+                const int32_t lo = d < b.dmin ? d : b.dmin, hi = d > b.dmax ? d : b.dmax;
+                if (hi - lo > span) break;
+                b.dmin = lo;
+                b.dmax = hi;
+                b.j1++;
+            }
+            moved += (size_t)(b.j1 - b.j0) * (size_t)(n + b.dmax - b.dmin) * (size_t)sample_width;
+            if (b.dmax - b.dmin > widest) widest = b.dmax - b.dmin;
+            ch.blocks.push_back(b);
+            j = b.j1;
+        }
+        // device rows P apart: wide enough that a widened row ends where the next one begins (row j of a run lands at j P + dmin and is
+        // n + dmax - dmin long); the frames themselves sit at j P + d_j, their drift accumulating as it does in the capture
+        ch.P = (int64_t)n + widest;
+        ch.stride2 = (double)ch.P + frac;
+        if (!((double)(ch.P + 1) * (double)width < 2147483000.0)) return false;       // the kernel's positions are int32
+        ch.pos2_x0 = spjs::to_int32(0.5 + ch.stride2 * (double)ch.x0);
+        for (int j = 0; j < rows; j++) {
+            const int64_t pos2 = spjs::to_int32(0.5 + ch.stride2 * (double)(ch.x0 + j));
+            if (pos2 - ch.pos2_x0 != (int64_t)j * ch.P + ch.drift[(size_t)j]) return false;   // the two sides of the identity rounded apart
+            if (j == rows - 1) ch.pos2_last = pos2;
+        }
+        ch.dev_off = off;
+        off += ((size_t)((int64_t)rows * ch.P + ch.drift[(size_t)rows - 1] + widest) * (size_t)sample_width + 255) & ~(size_t)255;
+        out.push_back(std::move(ch));
+    }
+    *dev_bytes = off + 256;
+    *link_bytes = moved;
+    // worth it only if clearly fewer bytes cross the link, and not in a hail of small copies
+    size_t copies = 0;
+    for (const PackedChunk &ch : out) copies += ch.blocks.size();
+    return !out.empty() && moved <= nbytes / 4 * 3 && copies <= 512;
+}
+
+// The pitched copies of one chunk, on `stream`.
+static hipError_t upload_packed_chunk(const PackedChunk &ch, int n, int sample_width, const uint8_t *bytes, size_t nbytes, uint8_t *stage,
+                                      hipStream_t stream)
+{
+    const size_t sw = (size_t)sample_width;
+    hipError_t e = hipSuccess;
+    for (const PackedBlock &b : ch.blocks) {
+        int32_t j1 = b.j1;
+        // the widened rows may reach past the capture's end in the request's very last rows: those travel one by one, exactly
+        while (j1 > b.j0 && (size_t)(ch.first + (int64_t)(j1 - 1) * ch.F + b.dmax + n) * sw > nbytes) j1--;
+        if (j1 > b.j0) {
+            const size_t row_bytes = (size_t)(n + b.dmax - b.dmin) * sw;
+            const uint8_t *src = bytes + (size_t)(ch.first + (int64_t)b.j0 * ch.F + b.dmin) * sw;
+            uint8_t *dst = stage + ch.dev_off + (size_t)((int64_t)b.j0 * ch.P + b.dmin) * sw;
+            if (j1 - b.j0 == 1) e = hipMemcpyAsync(dst, src, row_bytes, hipMemcpyHostToDevice, stream);
+            else e = hipMemcpy2DAsync(dst, (size_t)ch.P * sw, src, (size_t)ch.F * sw, row_bytes, (size_t)(j1 - b.j0), hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+        for (int32_t j = j1; j < b.j1; j++) {
+            const int32_t d = ch.drift[(size_t)j];
+            e = hipMemcpyAsync(stage + ch.dev_off + (size_t)((int64_t)j * ch.P + d) * sw, bytes + (size_t)(ch.first + (int64_t)j * ch.F + d) * sw,
+                               (size_t)n * sw, hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return e;
+}
+
 // sp_render / sp_render_strip: `image_width` is the width in frames of the image reply->rgba points into (the strip's own width for
 // sp_render); it only matters for the spectrogram layout, whose rows are image_width pixels apart.
 static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
@@ -960,8 +1104,7 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
     const size_t W = (size_t)width, n = (size_t)req->n, L = (size_t)req->lut_len;
     const size_t rgba_bytes = 4 * W * n;
     const size_t host_pitch = req->waterfall ? 4 * n : 4 * (size_t)image_width;   // bytes between rows of the caller's image
-    rc = ctx->in_bytes.reserve(nbytes + 16);
-    if (!rc) rc = ctx->out_rgba.reserve(rgba_bytes + 16);
+    rc = ctx->out_rgba.reserve(rgba_bytes + 16);
     // small outputs: [c_hist L u64][cb_hist 1000 u64][minmax 2 f64][gauges 3*W u8]
     const size_t small_u64 = L + SP_CB_HIST_SIZE + 2;
     DeviceBuffer &small = ctx->render_small;
@@ -988,10 +1131,57 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
     const spfmt::Format f = spfmt::describe(req->format);
     const double sample_count = (double)nbytes / (double)f.width;
     const double stride = width > 1 ? (sample_count - (double)req->n) / (double)(width - 1) : 0.0;
+    const bool stride_ok = stride >= 0.0 && std::isfinite(stride) && 0.5 + stride * (double)(width - 1) < 2147483000.0;
+    // a sparse request (stride > n, every frame inside the capture, the frame-loop kernel): only the frames' own samples are uploaded
+    bool sparse = stride_ok && width >= 2 && stride > (double)req->n && plan_kernel(plan) == 3 && !getenv("SPECTROPLOT_HIP_NO_PACKED_UPLOAD")
+                  && (size_t)(spjs::to_int32(0.5 + stride * (double)(width - 1)) + (int64_t)req->n) * (size_t)f.width <= nbytes;
+    std::vector<PackedChunk> packed;
+    std::vector<int32_t> bounds;
     int chunks = 1;
-    if (reply->rgba && width >= 1024 && nbytes + rgba_bytes >= ((size_t)16 << 20) && stride >= 0.0 && std::isfinite(stride)
-        && 0.5 + stride * (double)(width - 1) < 2147483000.0)
-        chunks = width >= 8192 ? 8 : 4;
+    size_t packed_dev_bytes = 0, packed_link_bytes = 0;
+    for (int attempt = sparse ? 0 : 1; attempt < 2; attempt++) {
+        const size_t in_est = attempt == 0 ? W * n * (size_t)f.width : nbytes;
+        chunks = 1;
+        // SPECTROPLOT_HIP_RENDER_CHUNKS=k overrides the count (2 .. 16), SPECTROPLOT_HIP_CHUNK_RATIO=r the size of a chunk relative to
+        // its neighbour (0.2 .. 1; 1 = equal chunks); both read once
+        static const int env_chunks = getenv("SPECTROPLOT_HIP_RENDER_CHUNKS") ? atoi(getenv("SPECTROPLOT_HIP_RENDER_CHUNKS")) : 0;
+        static const double env_ratio = getenv("SPECTROPLOT_HIP_CHUNK_RATIO") ? atof(getenv("SPECTROPLOT_HIP_CHUNK_RATIO")) : 0.0;
+        const double ratio = env_ratio >= 0.2 && env_ratio <= 1.0 ? env_ratio : 0.65;
+        const bool uneven = ratio < 1.0;
+        if (reply->rgba && width >= 1024 && in_est + rgba_bytes >= ((size_t)16 << 20) && stride_ok) {
+            chunks = in_est + rgba_bytes >= ((size_t)64 << 20) ? 6 : 4;
+            if (env_chunks >= 2 && env_chunks <= sp_context::kMaxChunks && width >= 32 * env_chunks) chunks = env_chunks;
+        }
+        // The busier direction of the link never pauses; what does not overlap it is one chunk's way in the other direction plus its
+        // render: the LAST chunk's image when the samples are the longer transfer, the FIRST chunk's samples when the image is.  So the
+        // chunks shrink (or grow) geometrically towards that end - each 0.65 of its neighbour, which also keeps the shorter direction
+        // from falling behind - instead of being equal (measured, config 2: 8 equal chunks 2.73 ms, pure two-way copy 2.37 ms; every
+        // additional copy call costs the link ~13 us, so few chunks).  Chunks end on multiples of 32 frames.
+        bounds.assign(1, 0);
+        if (chunks > 1 && uneven) {
+            const bool in_heavy = in_est >= rgba_bytes;
+            double w[sp_context::kMaxChunks], sum = 0, acc = 0;
+            for (int k = 0; k < chunks; k++) sum += (w[k] = std::pow(ratio, in_heavy ? k : chunks - 1 - k));
+            for (int k = 0; k + 1 < chunks; k++) {
+                acc += w[k];
+                const int32_t x = (int32_t)((int64_t)((double)width * acc / sum) & ~(int64_t)31);
+                if (x > bounds.back() && x < width) bounds.push_back(x);
+            }
+            bounds.push_back(width);
+            chunks = (int)bounds.size() - 1;
+        } else {
+            for (int k = 0; k < chunks; k++) bounds.push_back(k + 1 == chunks ? width : (int32_t)(((int64_t)width * (k + 1) / chunks) & ~(int64_t)31));
+        }
+        if (attempt == 0) {
+            sparse = build_packed_chunks(req->n, f.width, nbytes, width, stride, bounds, packed, &packed_dev_bytes, &packed_link_bytes)
+                     && (int)packed.size() == chunks;
+            if (sparse) break;
+            packed.clear();
+        }
+    }
+    ctx->last_upload_bytes = sparse ? packed_link_bytes : nbytes;
+    rc = ctx->in_bytes.reserve(sparse ? packed_dev_bytes : nbytes + 16);
+    if (rc) return fail(ctx, rc, "sp_render: out of memory");
     hipError_t e = hipSuccess;
     if (chunks > 1) {
         if (!ctx->copy_in) e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
@@ -1002,34 +1192,59 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
         }
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render streams");
     }
+    // a packed chunk as the kernel sees it: (virtual) sample 0 of its layout, a length that covers its last frame and one spare sample
+    // (3-byte samples are fetched as dwords), its stride
+    auto packed_source = [&](const PackedChunk &ch) {
+        PackedSource ps;
+        ps.bytes = (const uint8_t *)ctx->in_bytes.p + ch.dev_off - (size_t)ch.pos2_x0 * (size_t)f.width;
+        ps.nbytes = (size_t)(ch.pos2_last + (int64_t)req->n + 1) * (size_t)f.width;
+        ps.nbytes -= ps.nbytes % (size_t)f.elem;
+        ps.stride = ch.stride2;
+        return ps;
+    };
     // (nothing to clear: the kernels overwrite every histogram count, both range values and every gauge byte)
     if (chunks == 1) {
-        if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
-        rc = sp_plan_execute(plan, ctx->in_bytes.p, nbytes, width, &d);
+        if (sparse) {
+            e = upload_packed_chunk(packed[0], req->n, f.width, bytes, nbytes, (uint8_t *)ctx->in_bytes.p, s);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(s);
+                return hip_fail(ctx, e, "sp_render packed upload");
+            }
+            const PackedSource ps = packed_source(packed[0]);
+            rc = plan_execute_range(plan, ctx->in_bytes.p, nbytes, width, 0, width, true, true, &d, &ps);
+        } else {
+            if (nbytes) e = hipMemcpyAsync(ctx->in_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return hip_fail(ctx, e, "sp_render upload");
+            rc = sp_plan_execute(plan, ctx->in_bytes.p, nbytes, width, &d);
+        }
         if (rc) {
             (void)hipStreamSynchronize(s);
             return rc;
         }
     } else {
         size_t sent = 0;
-        int32_t x0 = 0;
         for (int k = 0; k < chunks; k++) {
-            const int32_t x1 = k + 1 == chunks ? width : (int32_t)(((int64_t)width * (k + 1) / chunks) & ~(int64_t)31);
-            size_t need = nbytes;
-            if (k + 1 < chunks) {
-                const int64_t last_start = spjs::to_int32(0.5 + stride * (double)(x1 - 1));          // worker.js:72
-                need = (size_t)(last_start + req->n) * (size_t)f.width;
-                if (need > nbytes) need = nbytes;
-            }
-            if (need > sent) {
-                e = hipMemcpyAsync((char *)ctx->in_bytes.p + sent, bytes + sent, need - sent, hipMemcpyHostToDevice, ctx->copy_in);
-                sent = need;
+            const int32_t x0 = bounds[(size_t)k], x1 = bounds[(size_t)k + 1];
+            PackedSource ps{};
+            if (sparse) {
+                e = upload_packed_chunk(packed[(size_t)k], req->n, f.width, bytes, nbytes, (uint8_t *)ctx->in_bytes.p, ctx->copy_in);
+                ps = packed_source(packed[(size_t)k]);
+            } else {
+                size_t need = nbytes;
+                if (k + 1 < chunks) {
+                    const int64_t last_start = spjs::to_int32(0.5 + stride * (double)(x1 - 1));          // worker.js:72
+                    need = (size_t)(last_start + req->n) * (size_t)f.width;
+                    if (need > nbytes) need = nbytes;
+                }
+                if (need > sent) {
+                    e = hipMemcpyAsync((char *)ctx->in_bytes.p + sent, bytes + sent, need - sent, hipMemcpyHostToDevice, ctx->copy_in);
+                    sent = need;
+                }
             }
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_arrived[k], ctx->copy_in);
             if (e == hipSuccess) e = hipStreamWaitEvent(s, ctx->ev_arrived[k], 0);
             if (e != hipSuccess) break;
-            rc = plan_execute_range(plan, ctx->in_bytes.p, nbytes, width, x0, x1, k == 0, k + 1 == chunks, &d);
+            rc = plan_execute_range(plan, ctx->in_bytes.p, nbytes, width, x0, x1, k == 0, k + 1 == chunks, &d, sparse ? &ps : nullptr);
             if (rc) break;
             e = hipEventRecord(ctx->ev_rendered[k], s);
             if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_out, ctx->ev_rendered[k], 0);
@@ -1045,7 +1260,6 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
                 }
                 if (e != hipSuccess) break;
             }
-            x0 = x1;
         }
         if (rc || e != hipSuccess) {
             (void)hipStreamSynchronize(ctx->copy_in);
@@ -1086,6 +1300,13 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
 extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply)
 {
     return render_host(ctx, req, bytes, nbytes, width, reply, width);
+}
+
+extern "C" int sp_context_last_upload_bytes(const sp_context *ctx, size_t *nbytes)
+{
+    if (!ctx || !nbytes) return SP_ERR_INVALID_ARG;
+    *nbytes = ctx->last_upload_bytes;
+    return SP_OK;
 }
 
 extern "C" int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width,

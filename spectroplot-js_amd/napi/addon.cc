@@ -38,6 +38,8 @@
 // One render at a time per handle: a second render on a handle whose first is still in flight throws (HipWorker serialises its own).
 #include <node_api.h>
 
+#include <chrono>
+
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -200,12 +202,14 @@ struct HostPool {
 };
 HostPool g_pool;
 
-// What V8 is told a reply image weighs: its size up to 16 MiB.  At full weight a config-2 reply (64 MiB) reaches the collector's
-// external-memory limit by itself: one mark-sweep per message (1.2 ms each, `node --trace-gc tools/js_dropin_bench.js`).  Capped, the
-// collector runs about every fourth large reply - as it does for 16 MiB replies anyway - and the pool holds five or six blocks
-// instead of two; the blocks still return by collection only.
+// What V8 is told a reply image weighs: its size up to 6 MiB.  At full weight a config-2 reply (64 MiB) reaches the collector's
+// external-memory limit by itself: one mark-sweep per message (1.2 ms each, `node --trace-gc tools/js_dropin_bench.js`).  Capped at
+// 16 MiB (rounds 2-4) the collector still ran about every fourth large reply, and its marking steps land in whatever allocates next:
+// 0.25-0.3 ms of an average config-2 message, seen as `_request` taking 280-350 us instead of 40 (tools/js_message_stages.js cfg2,
+// profiles/r05_host_path.txt).  At 6 MiB it runs about every tenth reply and the pool holds ten to twelve blocks (0.7 GiB of host
+// memory for 64-MiB replies) instead of five or six; the blocks still return by collection only.
 // SPECTROPLOT_HIP_REPLY_WEIGHT_MB changes the cap (a caller that holds many replies at once can raise it to their real size).
-const size_t g_reply_weight_cap = env_mib("SPECTROPLOT_HIP_REPLY_WEIGHT_MB", 16);
+const size_t g_reply_weight_cap = env_mib("SPECTROPLOT_HIP_REPLY_WEIGHT_MB", 6);
 inline int64_t reply_weight(size_t size) { return (int64_t)(size < g_reply_weight_cap ? size : g_reply_weight_cap); }
 struct PoolTag { size_t size; int pin; };
 void pool_free_cb(napi_env env, void *data, void *hint)
@@ -224,6 +228,8 @@ struct Job {
     int32_t gather = SP_GROUP_GATHER_DEVICE;   // ... and where its strips meet (req.gather: 'device' | 'host')
     std::string transport, note;
     double t_render = 0, t_gather = 0, t_download = 0;
+    // where the job's time went on the worker thread (microseconds): reply buffers from the pool, the library call
+    double us_take = 0, us_native = 0;
     sp_request req{};
     std::vector<double> window;
     std::vector<uint8_t> lut;
@@ -333,8 +339,22 @@ bool parse_request(napi_env env, napi_value handle, napi_value req, Job *j, bool
     return true;
 }
 
+inline double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void run_job_inner(Job *j);
 void run_job(Job *j)
 {
+    const double t0 = now_us();
+    run_job_inner(j);
+    j->us_native = now_us() - t0 - j->us_take;
+}
+
+void run_job_inner(Job *j)
+{
+    const double t_take0 = now_us();
     const size_t W = j->width > 0 ? (size_t)j->width : 0, n = j->req.n > 0 ? (size_t)j->req.n : 0;
     j->rgba_size = 4 * W * n + 1;
     j->rgba = (uint8_t *)g_pool.take(j->rgba_size, &j->rgba_pin);
@@ -343,6 +363,7 @@ void run_job(Job *j)
     j->gamp = (uint8_t *)calloc(W + 1, 1);
     j->c_hist.assign(j->req.lut_len > 0 ? (size_t)j->req.lut_len : 0, 0);
     j->cb_hist.assign(SP_CB_HIST_SIZE, 0);
+    j->us_take = now_us() - t_take0;
     if (!j->rgba || !j->gmin || !j->gmax || !j->gamp) {
         j->status = SP_ERR_NOMEM;
         j->error = "out of host memory";
@@ -414,6 +435,13 @@ napi_value make_reply(napi_env env, Job *j)
     };
     put_hist("c_hist", j->c_hist);
     put_hist("cB_hist", j->cb_hist);
+    {
+        napi_value st;
+        napi_create_object(env, &st);
+        napi_create_double(env, j->us_take, &v); napi_set_named_property(env, st, "take_us", v);
+        napi_create_double(env, j->us_native, &v); napi_set_named_property(env, st, "native_us", v);
+        napi_set_named_property(env, out, "stages", st);
+    }
     napi_create_double(env, j->minmax[0], &v); napi_set_named_property(env, out, "dBfs_min", v);
     napi_create_double(env, j->minmax[1], &v); napi_set_named_property(env, out, "dBfs_max", v);
     if (j->group) {

@@ -500,6 +500,39 @@ def test_large_host_requests_render_in_overlapped_chunks(pkg, ctx, fmt, lg, n, w
         _assert_same(got, want)
 
 
+SPARSE = [(f, 256, 18, 131, False) for f in ("CU4", "CS4", "CU8", "CS8", "CU12", "CS12", "CU16", "CS16", "CU32", "CS32", "CU64", "CS64", "CF32", "CF64")] + [
+    ("CS12", 64, 16, 300, True),          # short frames, many rows per pitched copy
+    ("CU8", 512, 0, 200, False),          # an integer stride: 3 * n (the length is made to fit below)
+    ("CF32", 1024, 22, 2048, False),      # the reference's interactive shape, scaled: four chunks, fractional stride (drift inside a chunk)
+    ("CS16", 1024, 24, 4096, True),       # ... waterfall layout, hop 4 n
+    ("CS12", 8192, 23, 96, False),        # a frame = the whole workgroup
+    ("CF32", 128, 21, 1500, False),       # stride ~ 11 n
+]
+
+
+@pytest.mark.parametrize("fmt,n,lg,width,wf", SPARSE, ids=lambda v: str(v))
+def test_sparse_requests_upload_only_the_frames_they_read(pkg, ctx, monkeypatch, fmt, n, lg, width, wf):
+    """stride > n (lib/worker.js:50, 70-75: the reference's loop skips the samples between frames): sp_render copies the frames as rows
+    of pitched copies into a packed device buffer and renders from there.  Bit-exact against the oracle, identical to the contiguous
+    upload (SPECTROPLOT_HIP_NO_PACKED_UPLOAD), and the bytes over the link are the frames' own plus the rows' widening (at most half)."""
+    S = (1 << lg) if lg else n + (width - 1) * 3 * n
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 77 + n, "step": 7321, "gshift": 9, "amp": 0.5, "namp": 0.02}, S)
+    win, weight = pyoracle.window("blackmanHarris", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+    sw = pkg.parse_format(fmt)[1]
+    for _ in range(2):
+        got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+        _assert_same(got, want)
+        sent = ctx.last_upload_bytes()
+        assert width * n * sw <= sent <= width * n * sw * 3 // 2 and sent <= data.size * 3 // 4, (sent, width * n * sw, data.size)
+    monkeypatch.setenv("SPECTROPLOT_HIP_NO_PACKED_UPLOAD", "1")
+    got = ctx.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+    _assert_same(got, want)
+    assert ctx.last_upload_bytes() == data.size
+
+
 def test_nonfinite_taper_is_exact(pkg, ctx):
     """A caller-supplied taper may hold infinities or NaN (options.windowF is any function).  Inf * 1 + Inf * 0 is NaN in the
     reference's first butterfly, so the kernels that skip the products of (1, 0) butterflies must not serve such a plan."""

@@ -12,8 +12,12 @@ ctx = pkg.Context(0)
 L = ctx.lib.L
 # python3 tools/host_path.py [cfg2 | cfg1]   (cfg1: 1 MSample cu8, n = 512: the small-message case)
 CFG = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-n, fmt, W = (512, "CU8", 2048) if CFG == "cfg1" else (1024, "CF32", 16384)
-S = W * n
+# sparse: the reference's interactive shape - config 2's capture at a screen-wide image (2048 frames, stride ~ 8 n): sp_render uploads the
+#         frames' own samples only; `sparse-off`: the same with SPECTROPLOT_HIP_NO_PACKED_UPLOAD=1 (the capture as it is)
+if CFG == "sparse-off":
+    os.environ["SPECTROPLOT_HIP_NO_PACKED_UPLOAD"] = "1"
+n, fmt, W = (512, "CU8", 2048) if CFG == "cfg1" else (1024, "CF32", 2048) if CFG.startswith("sparse") else (1024, "CF32", 16384)
+S = 1 << 24 if CFG.startswith("sparse") else W * n
 data = siggen.generate(fmt, {"kind": "trinoise", "seed": 0x5EED0001, "step": 7321, "gshift": 11, "amp": 0.5, "namp": 0.02}, S)
 win, weight = pkg.window("hann" if CFG == "cfg1" else "blackmanHarris", n)
 i = np.arange(256)
@@ -50,4 +54,5 @@ for name, inp, out, fresh in (("pageable request, fresh pageable reply", data, N
                               ("pageable request, page-locked reply", data, pin_out, False), ("page-locked request and reply", pin_in, pin_out, False)):
     ms, total = run(inp, out, fresh)
     assert total == W * n
-    print("sp_render " + CFG + ", %-42s %6.3f ms per request = %5.1f GB/s over PCIe both ways" % (name + ":", ms, (data.nbytes + 4 * W * n) / ms / 1e6))
+    sent = ctx.last_upload_bytes()
+    print("sp_render " + CFG + ", %-42s %6.3f ms per request = %5.1f GB/s over PCIe both ways (%.1f MiB of samples sent)" % (name + ":", ms, (sent + 4 * W * n) / ms / 1e6, sent / 2**20))

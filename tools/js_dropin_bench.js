@@ -12,7 +12,7 @@ const siggen = require(path.join(root, 'oracle', 'js', 'siggen.js'))
 const { HipWorker } = require(path.join(root, 'spectroplot-js_amd', 'js'))
 
 const GEN = { kind: 'trinoise', seed: 0x5EED0001, step: 7321, gshift: 11, amp: 0.5, namp: 0.02 }
-function message(format, S, n, windowName, pinned) {
+function message(format, S, n, windowName, pinned, width) {
     let bytes = siggen.generate(format, GEN, S, 0)
     if (pinned) {   // the same samples in a page-locked ArrayBuffer (HipWorker.allocBuffer), as js/render_file.js cuts its slices
         const p = new Uint8Array(HipWorker.allocBuffer(bytes.byteLength))
@@ -23,7 +23,7 @@ function message(format, S, n, windowName, pinned) {
     const cmap = []
     for (let i = 0; i < 256; i++) cmap.push([i, 255 - i, (i * 3) & 255])
     cmap[0] = [0, 0, 0]; cmap[255] = [255, 255, 255]
-    return { block_norm: 1.0 / weight, gain: 6, range: 30, cmap, n, windowc, width: S / n, offset: 0, buffer: bytes.buffer, format,
+    return { block_norm: 1.0 / weight, gain: 6, range: 30, cmap, n, windowc, width: width || S / n, offset: 0, buffer: bytes.buffer, format,
         channelMode: false, waterfall: false }
 }
 function ask(worker, m) {
@@ -37,9 +37,12 @@ async function main() {
     const worker = new HipWorker()
     const json = process.argv.includes('--json')
     const rows = []
-    for (const [name, format, log2s, n, win, pinned] of [['config 1', 'CU8', 20, 512, 'hann', false], ['config 2 / 4', 'CF32', 22, 1024, 'blackmanHarris', false],
-        ['config 2', 'CF32', 24, 1024, 'blackmanHarris', false], ['config 2, request buffer page-locked', 'CF32', 24, 1024, 'blackmanHarris', true]]) {
-        const m = message(format, 2 ** log2s, n, win, pinned)
+    // (the last two: config 2's capture at a screen-wide image, 2048 frames ~ 8 n apart - the reference's interactive shape
+    // (lib/worker.js:50, 70-75): sp_render uploads the frames' own samples only; with SPECTROPLOT_HIP_NO_PACKED_UPLOAD=1 the whole capture)
+    for (const [name, format, log2s, n, win, pinned, width] of [['config 1', 'CU8', 20, 512, 'hann', false], ['config 2 / 4', 'CF32', 22, 1024, 'blackmanHarris', false],
+        ['config 2', 'CF32', 24, 1024, 'blackmanHarris', false], ['config 2, request buffer page-locked', 'CF32', 24, 1024, 'blackmanHarris', true],
+        ['sparse', 'CF32', 24, 1024, 'blackmanHarris', false, 2048], ['sparse, request buffer page-locked', 'CF32', 24, 1024, 'blackmanHarris', true, 2048]]) {
+        const m = message(format, 2 ** log2s, n, win, pinned, width)
         // warm-up: plan creation, and the pool of reply images (a block is recycled once V8 has collected the reply that held it, and
         // page-locked when it comes round; a long-running viewer re-rendering at one size is in that state)
         const t_cold = process.hrtime.bigint()
@@ -62,7 +65,7 @@ async function main() {
         for (let i = 0; i < reps; i++) reply = await ask(worker, m)
         const gpu_ms = Number(process.hrtime.bigint() - t0) / 1e6 / reps
         let cpu_ms = null, same = null
-        if (log2s <= 22) {
+        if (log2s <= 22 || width) {
             O.render(m)
             t0 = process.hrtime.bigint()
             const ref = O.render(m)
