@@ -126,6 +126,7 @@ class Library:
             L.sp_group_last_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
             L.sp_group_root_bytes.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
             L.sp_render_strip.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply), i32]
+        if hasattr(L, "sp_context_last_upload_bytes"):
             L.sp_context_last_upload_bytes.argtypes = [vp, C.POINTER(sz)]
         L.sp_context_get_stream.argtypes = [vp, C.POINTER(vp)]
 
