@@ -202,6 +202,10 @@ void sp_plan_destroy(sp_plan *plan);
  * The reply's arrays must live in DEVICE memory of the context's device, c_hist / cb_hist / dbfs_minmax 8-byte aligned: the frame-loop
  * kernel clears them itself and its workgroups add their shares with device atomics (one kernel per call; no separate finish launch
  * for requests the frame loop covers).
+ * Not capturable: every launch carries the number of its request, which its workgroups compare with what workgroup 0 publishes once it
+ * has cleared the reply, so a launch replayed from a hipGraph would not wait.  A call on a stream that is being captured returns
+ * SP_ERR_UNSUPPORTED.  (The wait relies on workgroup 0 being dispatched with the first wave of workgroups, as the hardware does; it is
+ * bounded - a launch that never sees the number traps instead of hanging.)
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
 /*

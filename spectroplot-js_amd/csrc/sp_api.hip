@@ -666,6 +666,14 @@ static int plan_execute_range(sp_plan *plan, const void *d_bytes, size_t nbytes,
         return fail(ctx, SP_ERR_INVALID_ARG, "reply: c_hist, cb_hist and dbfs_minmax must be 8-byte aligned");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    {
+        // The request's number travels in the kernel arguments, and the frame loop's workgroups wait for workgroup 0 to publish it (the
+        // reply is cleared first): a captured launch replayed from a hipGraph would find the number already there.  Refused.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(ctx, SP_ERR_UNSUPPORTED, "sp_plan_execute cannot be captured into a hipGraph (every launch carries its request's number)");
+        (void)hipGetLastError();
+    }
 
     if (width == 0) {
         // nothing to draw; the reply keeps the loop's initial values (worker.js:35-36)

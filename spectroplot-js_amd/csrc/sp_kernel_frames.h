@@ -73,6 +73,11 @@ inline constexpr Tw16 kTw16Host[8] = {
     {-0x1.d906bcf328d46p-1, 0x1.87de2a6aea965p-2},
 };
 
+// a group's row pieces are written with non-temporal stores from this many frames per group on (4 bytes per frame and row)
+#ifndef SP_NT_MIN_GROUP
+#define SP_NT_MIN_GROUP 32
+#endif
+
 constexpr int kMmSlotsMax = 4;
 constexpr int kMaxCells = kLdsMaxLut + SP_CB_HIST_SIZE + 2;   // merged histogram cells (sp_host.h Thresholds)
 
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         }
     };
     // non-temporal stores where a group's row pieces are whole 128-byte lines (below)
-    auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, group_frames >= 32); };
+    auto drain = [&](const int x0, const int part, const int nparts) { drain_rows(x0, part, nparts, 0, group_frames, 0, kThreads, group_frames >= SP_NT_MIN_GROUP); };
     int drain_x0 = -1;
     int gpar = 0;   // parity of the workgroup's current group (s_amp)
     meet.arrive();   // the first re-distribution only waits (exchange<.., SECOND = false>)
@@ -1067,8 +1072,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
         if (tid == kThreads - 1) s_pre[kThreads * kPer] = base;
         lds_barrier();
         if (seen != la->seq) {
-            // (never in practice: workgroup 0 published the number tens of microseconds ago)
-            while (__hip_atomic_load(la->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != la->seq) __builtin_amdgcn_s_sleep(8);
+            // (never in practice: workgroup 0 - dispatched first: the lowest workgroup number - published the number tens of microseconds
+            // ago.  The wait is bounded: ~2 s of polling end in a trap, i.e. a failed launch, instead of a hung device.)
+            unsigned polls = 0;
+            while (__hip_atomic_load(la->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != la->seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++polls > (1u << 22)) __builtin_trap();
+            }
         }
         const int sp0 = a.cells - 2, sp1 = a.cells - 1;                       // -inf / NaN dB (colour 0, bin 0); +inf dB (last colour, bin 0)
         const unsigned int n0 = s_pre[sp0 + 1] - s_pre[sp0], n1 = s_pre[sp1 + 1] - s_pre[sp1];

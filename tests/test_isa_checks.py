@@ -122,3 +122,21 @@ def test_the_prologue_waits_for_its_tables_not_for_the_first_frames_samples():
                     seen += 1
                 kernel = None
     assert seen >= 5 * 5          # five prefetch widths at n = 64 .. 1024
+
+
+def test_the_instrumentation_patch_applies_to_the_kernel_sources():
+    """tools/experiments/frames_instrumentation.patch (per-wave clocks for tools/stamps.py, cost-attribution switches, the round-5 tile
+    prototype) lives outside the product sources and is applied to a copy by tools/build_variant.sh: a kernel change that moves its
+    context must refresh it, or the next round finds its measuring tools broken."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) here")
+    with tempfile.TemporaryDirectory() as t:
+        os.makedirs(os.path.join(t, "spectroplot-js_amd"))
+        shutil.copytree(os.path.join(ROOT, "spectroplot-js_amd", "csrc"), os.path.join(t, "spectroplot-js_amd", "csrc"))
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(t, "include"))
+        with open(os.path.join(ROOT, "tools", "experiments", "frames_instrumentation.patch")) as fh:
+            r = subprocess.run(["patch", "-p1", "--dry-run", "-s"], cwd=t, stdin=fh, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]

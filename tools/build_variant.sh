@@ -10,7 +10,7 @@ REPO=$(cd $(dirname $0)/.. && pwd)
 ROOT=$REPO/spectroplot-js_amd
 SRC=$ROOT
 case "$EXTRA" in
-  *SP_STAMPS*|*SP_ABL_*|*SP_EXPERIMENT_KNOBS*)
+  *SP_STAMPS*|*SP_ABL_*|*SP_PROTO_*|*SP_EXPERIMENT_KNOBS*)
     SRC=/tmp/sp_src_$NAME
     rm -rf $SRC && mkdir -p $SRC/spectroplot-js_amd $SRC/include
     cp -r $ROOT/csrc $ROOT/Makefile $SRC/spectroplot-js_amd/ && cp $REPO/include/*.h $SRC/include/

@@ -103,16 +103,23 @@ def main(objs):
         # (a toolchain without the disassembler: nothing can be checked, and a build must not fail for that)
         print("check_lds_reads: llvm-objdump / clang-offload-bundler / objcopy not found, nothing checked (set HIPCC or ROCM_PATH)")
         return 0
-    bad, kernels, reads = [], 0, 0
+    bad, kernels, reads, empty = [], 0, 0, []
     for o in objs:
         lines = disassemble(o)
-        kernels += sum(1 for ln in lines if re.match(r"^[0-9a-f]+ <.*>:", ln))
+        k = sum(1 for ln in lines if re.match(r"^[0-9a-f]+ <.*>:", ln))
+        kernels += k
+        # a frame-loop object without a single kernel for ARCH (wrong --offload-arch, a bundle this tool cannot read) would pass with
+        # nothing checked: that is a failure of the gate, not a pass (host-only objects are not frames_*.o)
+        if k == 0 and os.path.basename(o).startswith("frames_"):
+            empty.append(os.path.basename(o))
         reads += sum(1 for ln in lines if re.search(r"\sds_read_b64\s", ln))
         bad += check_listing(lines, os.path.basename(o))
     print("check_lds_reads: %d objects, %d kernels, %d ds_read_b64, %d violations" % (len(objs), kernels, reads, len(bad)))
     for b in bad[:40]:
         print("  " + b)
-    return 1 if bad else 0
+    if empty:
+        print("check_lds_reads: no %s kernels found in %s: nothing was checked there" % (ARCH, ", ".join(empty)))
+    return 1 if bad or empty else 0
 
 
 if __name__ == "__main__":
