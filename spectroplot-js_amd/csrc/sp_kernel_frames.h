@@ -906,7 +906,6 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                     float tg[EB], tc[EB];
                     int gi[EB], cell[EB];
                     unsigned cell4[EB];              // 4 * (colour index + level): the byte offset of the pixel's merged cell
-                    bool risky[EB];
                     float worst = 0.0f;   // largest fractional part of the batch, either scale
                     // written stage by stage: the four chains are independent, and every step of a chain waits on the one before
                     float l2[EB];
@@ -944,33 +943,31 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         cell4[k] = (unsigned)(cell[k] + gi[k]) << 2;                   // one v_add_lshl_u32
                     }
                     if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
-#pragma unroll
-                        for (int k = 0; k < EB; k++)
-                            risky[k] = !(__builtin_amdgcn_fractf(tg[k]) < thr) || !(__builtin_amdgcn_fractf(tc[k]) < thr);
-                        // nearest edge on either scale for every lane (one batch of reads, one wait), then one exact comparison
-                        // each; only the risky lanes keep the result (edges: sp_host.h Thresholds)
-                        int rg[EB], rc[EB];
-                        double eg[EB], ec[EB];
+                        // Rare (one batch in eleven), and nearly always for ONE lane on ONE bin and ONE scale: each (bin, scale) is
+                        // decided on its own - the nearest edge of that scale for every lane (one LDS read, one exact comparison),
+                        // only the risky lanes keep the result (edges: sp_host.h Thresholds) - so a typical visit costs a quarter
+                        // of deciding everything for the whole batch.
 #pragma unroll
                         for (int k = 0; k < EB; k++) {
-                            rg[k] = min(max((int)rintf(tg[k] + g_m), 1), cmax);
-                            rc[k] = min(max((int)rintf(tc[k] + c_m), 1), SP_CB_HIST_SIZE);
-                            eg[k] = edge_g[rg[k]];
-                            ec[k] = edge_cb[rc[k]];
-                        }
-#pragma unroll
-                        for (int k = 0; k < EB; k++) {
-                            int g = abs2[k] >= eg[k] ? rg[k] : rg[k] - 1;
-                            int c = g + (abs2[k] >= ec[k] ? rc[k] : rc[k] - 1);
-                            // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
-                            if (!(abs2[k] > 0.0)) {
-                                g = 0;
-                                c = cell_sp0;
-                            } else if (abs2[k] == spjs::inf()) {
-                                c = cell_sp0 + 1;
+                            const bool rgk = !(__builtin_amdgcn_fractf(tg[k]) < thr), rck = !(__builtin_amdgcn_fractf(tc[k]) < thr);
+                            int lev = cell[k], spc = -1;
+                            if (__ballot(rgk) != 0ull) {
+                                const int r = min(max((int)rintf(tg[k] + g_m), 1), cmax);
+                                const int g = abs2[k] >= edge_g[r] ? r : r - 1;
+                                gi[k] = rgk ? g : gi[k];
                             }
-                            gi[k] = risky[k] ? g : gi[k];
-                            cell4[k] = risky[k] ? (unsigned)c << 2 : cell4[k];
+                            if (__ballot(rck) != 0ull) {
+                                const int r = min(max((int)rintf(tc[k] + c_m), 1), SP_CB_HIST_SIZE);
+                                const int l = abs2[k] >= edge_cb[r] ? r : r - 1;
+                                // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
+                                // (the clamp bounds of the level scale are risky by construction, so these lanes always come here)
+                                const bool dark = !(abs2[k] > 0.0), bright = abs2[k] == spjs::inf();
+                                const int s = dark ? cell_sp0 : bright ? cell_sp0 + 1 : -1;
+                                lev = rck ? l : lev;
+                                spc = rck ? s : spc;
+                                gi[k] = rck && dark ? 0 : gi[k];
+                            }
+                            cell4[k] = spc >= 0 ? (unsigned)spc << 2 : (unsigned)(gi[k] + lev) << 2;
                         }
                     }
 #pragma unroll

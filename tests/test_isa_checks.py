@@ -7,6 +7,8 @@ import glob
 import importlib.util
 import os
 
+import pytest
+
 from __graft_entry__ import ROOT, build
 
 
