@@ -221,7 +221,7 @@ def rocprof_hbm_bytes(argv_config):
 
 def valu_roofline(config, kernel_us, frames):
     """The resource that binds the frame loop in fact: VALU issue.  Counted wave-instructions per launch (rocprofv3
-    --pmc, committed under profiles/) times the measured issue cost of their class with two waves per SIMD (profiles/r02_op_cost.txt),
+    --pmc, committed under profiles/) times the measured issue cost of their class with two waves per SIMD (profiles/r05_op_cost.txt),
     over the chip's 1024 SIMDs at 2.4 GHz: the time the launch would take if no SIMD ever waited."""
     f, tag = None, None
     for tag in PROFILE_TAGS:
@@ -238,7 +238,12 @@ def valu_roofline(config, kernel_us, frames):
     cvt, trans, i32 = g("SQ_INSTS_VALU_CVT"), g("SQ_INSTS_VALU_TRANS_F32"), g("SQ_INSTS_VALU_INT32") + g("SQ_INSTS_VALU_INT64")
     f32 = g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
     other = max(g("SQ_INSTS_VALU") - f64 - cvt - trans - i32 - f32, 0.0)
-    cost = {"f64": 4.7, "cvt": 4.6, "trans_f32": 8.8, "int": 2.5, "f32": 3.0, "other": 4.5}   # cycles per wave-instruction per SIMD
+    # cycles per wave-instruction per SIMD with two waves per SIMD (profiles/r05_op_cost.txt).  Round 5 measured more instructions than
+    # rounds 2-4 had: nearly EVERY VALU instruction costs 4.6-4.9 - shifts, v_add_lshl_u32, v_lshl_or_b32, v_med3, SDWA forms, conversions
+    # and the f64 operations alike; only v_add_u32 / v_mul_f32 (2.5) and v_fma_f32 (3.5) are cheaper, v_log_f32 (8.8) and the permlane
+    # swaps (8.1) dearer.  The integer and f32 classes are mixes of those (the PMC classes do not separate them); "other" holds the
+    # swaps (64 of ~290 per 1024-point frame).
+    cost = {"f64": 4.7, "cvt": 4.8, "trans_f32": 8.8, "int": 4.0, "f32": 3.6, "other": 5.0}
     cycles = f64 * cost["f64"] + cvt * cost["cvt"] + trans * cost["trans_f32"] + i32 * cost["int"] + f32 * cost["f32"] + other * cost["other"]
     floor_us = cycles / 1024.0 / 2400.0
     return {"bound": "f64 VALU issue", "f64_wave_insts": f64, "f64_wave_insts_per_frame_wave": f64 / max(frames, 1), "fused_f64_insts": g("SQ_INSTS_VALU_FMA_F64"),
@@ -247,7 +252,7 @@ def valu_roofline(config, kernel_us, frames):
             "fused_f64_note": "v_fma_f64 belongs to the IEEE divisions of the side outputs' software log10 and gauge scaling (a few per group of "
                               "frames); the transform's multiplies and adds are all separate instructions",
             "floor_us": floor_us, "kernel_us": kernel_us, "frac": floor_us / kernel_us if kernel_us else None,
-            "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r02_op_cost.txt" % (tag, config)}
+            "source": "profiles/%s_%s_valu.json (rocprofv3 --pmc of this command); issue costs: profiles/r05_op_cost.txt" % (tag, config)}
 
 
 def launch_ranks(argv, gpus):

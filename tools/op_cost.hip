@@ -5,10 +5,14 @@
 #include <cstdio>
 
 #define CHAINS 16
-enum { MUL64, ADD64, MULADD64, FMA64, MULS64, MAX64, CVT64_32, CVT32_64, FMA32, MUL32, LOG32, FLR32, FRACT32, MED332, SWAP32, CNDMASK, ADDU32, CMPF32, CMPF64, NOPS };
+enum { MUL64, ADD64, MULADD64, FMA64, MULS64, MAX64, CVT64_32, CVT32_64, FMA32, MUL32, LOG32, FLR32, FRACT32, MED332, SWAP32, CNDMASK, ADDU32, CMPF32, CMPF64,
+       CVTU32, MED3U32, MAX3F32, MAXSDWA, ADDSDWA, MOVSDWA, LSHLSDWA, ADDLSHL, LSHLOR, LSHL32, PKFMA32, READFL, NOPS };
 static const char *names[] = {"v_mul_f64", "v_add_f64", "mul+add f64", "v_fma_f64", "v_mul_f64 sgpr", "v_max_f64", "v_cvt_f64_f32", "v_cvt_f32_f64",
                               "v_fma_f32", "v_mul_f32", "v_log_f32", "v_cvt_flr_i32_f32", "v_fract_f32", "v_med3_f32", "v_permlane32_swap",
-                              "v_cndmask_b32", "v_add_u32", "v_cmp_gt_f32", "v_cmp_ge_f64"};
+                              "v_cndmask_b32", "v_add_u32", "v_cmp_gt_f32", "v_cmp_ge_f64",
+                              // round 5: what a fixed-point epilogue would be made of, and the instructions the census changed
+                              "v_cvt_u32_f32", "v_med3_u32", "v_max3_f32", "v_max_u32_sdwa W0", "v_add_u32_sdwa W1", "v_mov_b32_sdwa B",
+                              "v_lshlrev_sdwa B1", "v_add_lshl_u32", "v_lshl_or_b32", "v_lshlrev_b32", "v_pk_fma_f32", "v_readfirstlane"};
 
 template <int OP>
 __global__ void k(double *out, unsigned long long *clk, int iters, double sc)
@@ -53,6 +57,18 @@ __global__ void k(double *out, unsigned long long *clk, int iters, double sc)
                 if (OP == ADDU32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(f[i]));
                 if (OP == CMPF32) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(f[i]), "v"(g[i]) : "vcc");
                 if (OP == CMPF64) asm volatile("v_cmp_ge_f64 vcc, %0, %1" : : "v"(a[i]), "v"(b[i]) : "vcc");
+                if (OP == CVTU32) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(u[i]) : "v"(g[i]));
+                if (OP == MED3U32) asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(f[i]), "v"(g[i]));
+                if (OP == MAX3F32) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(g[i]), "v"(g[(i + 1) % CHAINS]));
+                if (OP == MAXSDWA) asm volatile("v_max_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(u[i]) : "v"(f[i]));
+                if (OP == ADDSDWA) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(u[i]) : "v"(f[i]), "v"(g[i]));
+                if (OP == MOVSDWA) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(u[i]) : "v"(f[i]));
+                if (OP == LSHLSDWA) asm volatile("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(u[i]) : "v"(f[i]));
+                if (OP == ADDLSHL) asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(u[i]) : "v"(f[i]));
+                if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %1, 8, %0" : "+v"(u[i]) : "v"(f[i]));
+                if (OP == LSHL32) asm volatile("v_lshlrev_b32 %0, 2, %1" : "=v"(u[i]) : "v"(f[i]));
+                if (OP == PKFMA32) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == READFL) { unsigned sx; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(u[i])); asm volatile("" ::"s"(sx)); }
             }
         }
     }

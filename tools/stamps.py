@@ -26,8 +26,17 @@ d_in = ctx.alloc(S * sw)
 ctx.synth_trinoise(d_in, fmt, 0, S, bench.GEN["seed"], bench.GEN["step"], bench.GEN["gshift"], bench.GEN["amp"], bench.GEN["namp"])
 L = len(lut)
 ptrs = [ctx.alloc(max(s, 16)) for s in (4 * W * n, W, W, W, 8 * L, 8000, 16)]
-for _ in range(300):
-    plan.execute(d_in, S * sw, W, *ptrs)
+# SP_STAMPS_ROTATE=K: K capture / image sets in rotation (the stamped launch - the last one - then streams through HBM instead of
+# finding its capture and its image in the Infinity Cache)
+ROT = int(os.environ.get("SP_STAMPS_ROTATE", "1"))
+sets = [(d_in, ptrs[0])]
+for k in range(1, ROT):
+    di = ctx.alloc(S * sw)
+    ctx.synth_trinoise(di, fmt, k * S, S, bench.GEN["seed"], bench.GEN["step"], bench.GEN["gshift"], bench.GEN["amp"], bench.GEN["namp"])
+    sets.append((di, ctx.alloc(4 * W * n)))
+for i in range(300):
+    di, img = sets[i % ROT]
+    plan.execute(di, S * sw, W, img, *ptrs[1:])
 ctx.synchronize()
 waves = 8 if n > 1024 else int(os.environ.get("SP_WAVES", "8"))
 cnt = 256 * waves * 24
