@@ -195,6 +195,16 @@ __device__ inline void store_nt(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c
     __builtin_nontemporal_store(v, (u32x4 *)dst);
 }
 
+// 16-byte store at a wave-uniform base + a 32-bit lane offset: `global_store_dwordx4 voff, data, s[base]`.  From `base + off` the
+// compiler builds the 64-bit address in the VALU (a v_mov of the zero high half and a v_lshl_add_u64 per store).
+__device__ inline void store16_at(uint8_t *base, unsigned off, uint32_t a, uint32_t b, uint32_t c, uint32_t d, bool nt)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {a, b, c, d};
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+
 // LDS accesses at a compile-time offset plus a byte offset held in a VGPR, through a pointer made from the integer (the dynamic LDS
 // block starts at address 0: k_frames has no static LDS and checks it once): `ds_* vaddr offset:imm`.  Going through `smem + ...`
 // instead leaves a `v_add_u32 v, 0, v` per access behind - the block's address is only replaced by its value after the last folding pass.
@@ -523,7 +533,13 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
     // VGPR again for every batch of bins (24 v_mov per frame).  The addends and the upper clamp bound live in VGPRs instead.
     // (n <= 1024, where registers are left: above, the loop sits at the 256-VGPR limit and three more spill)
     float g_a_v = g_a, c_a_v = c_a, c_hi_v = c_hi;
-    if constexpr (LOG2N <= 10 && !CH && !(PFB == 8 && LOG2N < 9)) asm volatile("" : "+v"(g_a_v), "+v"(c_a_v), "+v"(c_hi_v));
+    constexpr bool COEF_VGPR = LOG2N <= 10 && !CH && !(PFB == 8 && LOG2N < 9);
+    if constexpr (COEF_VGPR) asm volatile("" : "+v"(g_a_v), "+v"(c_a_v), "+v"(c_hi_v));
+    // ... and, at n = 1024, both scales of a batch's two bins as packed pairs (below that size the loop measures the same with and
+    // without, and the launch-bound config 1 pays 1 % for the longer set-up: profiles/r05_experiments.txt)
+    constexpr bool PK_SCALES = COEF_VGPR && LOG2N == 10;
+    [[maybe_unused]] f32x2 g_b2 = {g_b, g_b}, g_a2 = {g_a, g_a}, c_b2 = {c_b, c_b}, c_a2 = {c_a, c_a};
+    if constexpr (PK_SCALES) asm volatile("" : "+v"(g_b2), "+v"(g_a2), "+v"(c_b2), "+v"(c_a2));
     // clamp bounds of the colour value: clipped pixels sit in the middle of the first / last step, far from the risky zone
     const float g_lo = 0.5f, g_hi = (float)cmax + 0.5f;
     const int cell_sp0 = a.cells - 2;   // -inf / NaN dB (colour 0, bin 0), +inf dB is the next one (last colour, bin 0)
@@ -631,8 +647,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                                 // 128-byte lines, so that the image does not displace the capture's lines in L2 (measured: 2.5 % of the
                                 // kernel at n = 1024); shorter segments (large n) are pieces of lines that L2 has to merge with the
                                 // neighbouring groups' pieces (non-temporal there doubled the HBM traffic)
-                                if (nt_rows) store_nt(img + off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
-                                else *(uint4 *)(img + off) = make_uint4(px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3]);
+                                store16_at(img, off, px[u][j][0], px[u][j][1], px[u][j][2], px[u][j][3], nt_rows);
                             }
                         }
                         continue;
@@ -898,7 +913,9 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
             uint32_t *trow = (uint32_t *)(s_tile + fr * tile_pitch + tl * 16);
             if (live) {
                 constexpr int EB = 2;   // bins per batch
-                uint32_t tile_word = 0;          // four colour bytes per tile dword
+                [[maybe_unused]] uint32_t tile_word = 0;          // four colour bytes per tile dword
+                constexpr bool TILE_BYTES = LOG2N == 10;         // (other sizes: no gain measured below, not measured above)
+                [[maybe_unused]] const unsigned trow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) uint32_t *)trow;
                 // a batch of bins at a time: independent chains for the VALU, one branch per batch, four colour bytes per tile dword
 #pragma unroll
                 for (int q = 0; q < 16 / EB; q++) {
@@ -920,10 +937,20 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         mn4[k & 3] = min_raw(mn4[k & 3], abs2[k]);
                         mx4[k & 3] = max_raw(mx4[k & 3], abs2[k]);
                     }
+                    if constexpr (PK_SCALES) {
+                        // one v_pk_fma_f32 per scale for the batch's two bins (4.7 issue cycles instead of 2 x 3.5, one instruction
+                        // fewer per bin); each half rounds like v_fma_f32
+                        static_assert(EB == 2, "a packed fma takes the batch's two bins");
+                        const f32x2 lp = {l2[0], l2[1]};
+                        const f32x2 tgp = __builtin_elementwise_fma(g_b2, lp, g_a2), tcp = __builtin_elementwise_fma(c_b2, lp, c_a2);
+                        tg[0] = tgp.x; tg[1] = tgp.y;
+                        tc[0] = tcp.x; tc[1] = tcp.y;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < EB; k++) {
-                        tg[k] = fmaf(g_b, l2[k], g_a_v);
-                        tc[k] = fmaf(c_b, l2[k], c_a_v);
+                        for (int k = 0; k < EB; k++) {
+                            tg[k] = fmaf(g_b, l2[k], g_a_v);
+                            tc[k] = fmaf(c_b, l2[k], c_a_v);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
@@ -940,7 +967,6 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                         // (the clamps have turned a NaN into a bound, so the fractional parts are numbers; one threshold, the
                         // smaller of the two, serves both scales)
                         worst = fmaxf(fmaxf(worst, __builtin_amdgcn_fractf(tg[k])), __builtin_amdgcn_fractf(tc[k]));   // one v_max3_f32
-                        cell4[k] = (unsigned)(cell[k] + gi[k]) << 2;                   // one v_add_lshl_u32
                     }
                     if (__builtin_expect(__ballot(!(worst < thr)) != 0ull, 0)) {
                         // Rare (one batch in eleven), and nearly always for ONE lane on ONE bin and ONE scale: each (bin, scale) is
@@ -950,7 +976,7 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
 #pragma unroll
                         for (int k = 0; k < EB; k++) {
                             const bool rgk = !(__builtin_amdgcn_fractf(tg[k]) < thr), rck = !(__builtin_amdgcn_fractf(tc[k]) < thr);
-                            int lev = cell[k], spc = -1;
+                            int lev = cell[k];
                             if (__ballot(rgk) != 0ull) {
                                 const int r = min(max((int)rintf(tg[k] + g_m), 1), cmax);
                                 const int g = abs2[k] >= edge_g[r] ? r : r - 1;
@@ -961,20 +987,29 @@ __global__ __launch_bounds__(kFrameThreads, 1) void k_frames(const FrameArgs a, 
                                 const int l = abs2[k] >= edge_cb[r] ? r : r - 1;
                                 // -inf / NaN dB: colour 0; +inf dB: last colour; all three: ToInt32 gives key 0 = bin 0      worker.js:105,111
                                 // (the clamp bounds of the level scale are risky by construction, so these lanes always come here)
+                                // (their cells lie behind the regular ones: the level is set so that colour index + level names them)
                                 const bool dark = !(abs2[k] > 0.0), bright = abs2[k] == spjs::inf();
-                                const int s = dark ? cell_sp0 : bright ? cell_sp0 + 1 : -1;
-                                lev = rck ? l : lev;
-                                spc = rck ? s : spc;
                                 gi[k] = rck && dark ? 0 : gi[k];
+                                lev = rck ? (dark ? cell_sp0 : bright ? cell_sp0 + 1 - gi[k] : l) : lev;
                             }
-                            cell4[k] = spc >= 0 ? (unsigned)spc << 2 : (unsigned)(gi[k] + lev) << 2;
+                            cell[k] = lev;
                         }
                     }
+                    // the merged cell's byte offset, 4 * (colour index + level), as ONE instruction (left to the compiler it becomes an
+                    // add on one side of the branch above and a shift on the other)
+#pragma unroll
+                    for (int k = 0; k < EB; k++) asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(cell4[k]) : "v"(gi[k]), "v"(cell[k]));
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
                         const int e = EB * q + k;                 // compile-time after unrolling
-                        tile_word = (e & 3) == 0 ? (uint32_t)gi[k] : tile_word | ((uint32_t)gi[k] << (8 * (e & 3)));
-                        if ((e & 3) == 3) trow[e >> 2] = tile_word;
+                        if constexpr (TILE_BYTES) {
+                            // one ds_write_b8 per bin (base + immediate): packing four indices into a dword first costs three
+                            // v_lshl_or_b32 per dword, and every VALU instruction costs what an f64 operation costs; the LDS pipe has room
+                            asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(trow_addr), "v"(gi[k]), "n"(e) : "memory");
+                        } else {
+                            tile_word = (e & 3) == 0 ? (uint32_t)gi[k] : tile_word | ((uint32_t)gi[k] << (8 * (e & 3)));
+                            if ((e & 3) == 3) trow[e >> 2] = tile_word;
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < EB; k++) {
