@@ -99,12 +99,15 @@ def e2e_dropin():
         return {"workload": "one config-2 worker message (16 MSample cf32 in, 64 MiB RGBA out) through HipWorker under Node",
                 "ms_per_message": a["ms_per_message"], "msamples_per_s": a["msamples_per_s"], "first_message_ms": a.get("first_message_ms"),
                 "ms_per_message_pinned_request": b["ms_per_message"], "msamples_per_s_pinned_request": b["msamples_per_s"],
+                # mean over `messages` back-to-back messages (V8's collector pauses included) and their median
+                "messages": a.get("messages"), "median_ms_per_message": a.get("median_ms_per_message"),
+                "median_ms_per_message_pinned_request": b.get("median_ms_per_message"),
                 "config1_ms_per_message": pick["config 1"]["ms_per_message"], "config1_js_worker_ms": pick["config 1"]["js_worker_ms"],
                 # the longer direction of a config-2 message (128 MiB in, 64 MiB out, full duplex) against the host link's 63 GB/s
                 "pcie_frac": (128 * 2**20) / (b["ms_per_message"] * 1e-3) / 63e9,
                 "pcie_frac_note": "134 MB of samples per message / ms_per_message_pinned_request / 63 GB/s (PCIe Gen5 x16, one direction)",
                 # the same capture at a screen-wide image (2048 frames, stride ~ 8 n: lib/worker.js:50, 70-75): only the frames' samples travel
-                "sparse_ms_per_message": pick["sparse"]["ms_per_message"],
+                "sparse_ms_per_message": pick["sparse"]["ms_per_message"], "sparse_median_ms_per_message": pick["sparse"].get("median_ms_per_message"),
                 "sparse_ms_per_message_pinned_request": pick["sparse, request buffer page-locked"]["ms_per_message"],
                 "sparse_images_identical_to_js_worker": pick["sparse"]["images_identical"],
                 "sparse_note": "16 MSample cf32, n = 1024, width 2048: the frames' own 16 MiB (+ the pitched rows' widening) cross the link "

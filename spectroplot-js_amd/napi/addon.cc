@@ -124,7 +124,8 @@ void ctx_release(Ctx *x)
 // A block that comes round a second time is page-locked (on the worker thread, once): copies into it then run asynchronously at
 // the rate of the host link, which is what lets sp_render overlap the image's way back with the samples' way in.
 // Limits, each read once from the environment (MiB): SPECTROPLOT_HIP_POOL_KEEP_MB bounds the dropped blocks kept for reuse (default
-// 3072), SPECTROPLOT_HIP_POOL_PINNED_MB the page-locked bytes of pool blocks, free or held by JavaScript (default 1024; 0 = never
+// 3072), SPECTROPLOT_HIP_POOL_PINNED_MB the page-locked bytes of pool blocks, free or held by JavaScript (default 2048 - ten to twelve
+// 64-MiB replies are alive between two collections, and a reply in a block that is not page-locked takes 4.0 instead of 2.7 ms; 0 = never
 // page-lock), SPECTROPLOT_HIP_REPLY_WEIGHT_MB what V8 is told a reply weighs at most (below).
 inline size_t env_mib(const char *name, size_t dflt_mib)
 {
@@ -142,7 +143,7 @@ struct HostPool {
     size_t free_bytes = 0, pinned_bytes = 0;
     size_t n_fresh = 0, n_recycled = 0, n_recycled_pinned = 0, n_pin_refused = 0;   // poolStats()
     const size_t keep_bytes = env_mib("SPECTROPLOT_HIP_POOL_KEEP_MB", 3072);
-    const size_t pinned_limit = env_mib("SPECTROPLOT_HIP_POOL_PINNED_MB", 1024);
+    const size_t pinned_limit = env_mib("SPECTROPLOT_HIP_POOL_PINNED_MB", 2048);
     void *take(size_t size, int *pin)
     {
         *pin = kUnpinned;

@@ -59,11 +59,15 @@ async function main() {
             calm = f === fresh ? calm + 1 : 0
             fresh = f
         }
-        const reps = 24
+        // mean AND median over enough messages that V8's collector (a pause every ~10th large reply) weighs what it weighs
+        const reps = log2s >= 24 ? 96 : 48
         let t0 = process.hrtime.bigint()
         let reply
-        for (let i = 0; i < reps; i++) reply = await ask(worker, m)
+        const each = []
+        for (let i = 0; i < reps; i++) { const t1 = process.hrtime.bigint(); reply = await ask(worker, m); each.push(Number(process.hrtime.bigint() - t1) / 1e6) }
         const gpu_ms = Number(process.hrtime.bigint() - t0) / 1e6 / reps
+        each.sort((a, b) => a - b)
+        const median_ms = each[each.length >> 1]
         let cpu_ms = null, same = null
         if (log2s <= 22 || width) {
             O.render(m)
@@ -72,7 +76,7 @@ async function main() {
             cpu_ms = Number(process.hrtime.bigint() - t0) / 1e6
             same = Buffer.compare(Buffer.from(ref.imageData.data.buffer), Buffer.from(reply.imageData.data.buffer)) === 0
         }
-        rows.push({ name, format, samples: 2 ** log2s, n, request_buffer: pinned ? 'page-locked' : 'pageable', ms_per_message: gpu_ms, first_message_ms: cold_ms,
+        rows.push({ name, format, samples: 2 ** log2s, n, request_buffer: pinned ? 'page-locked' : 'pageable', ms_per_message: gpu_ms, median_ms_per_message: median_ms, messages: reps, first_message_ms: cold_ms,
             warmup_messages: warm,
             msamples_per_s: 2 ** log2s / gpu_ms / 1e3, js_worker_ms: cpu_ms, images_identical: same })
         if (!json) console.log(`${name}: ${format} 2^${log2s} samples, n=${n}: HipWorker ${gpu_ms.toFixed(2)} ms per message` +
