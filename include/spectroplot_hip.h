@@ -272,6 +272,8 @@ int sp_group_render_ex(sp_group *group, const sp_request *req, const uint8_t *by
 const char *sp_group_transport(const sp_group *group);
 const char *sp_group_transport_note(const sp_group *group);
 int sp_group_last_timings(const sp_group *group, double *render_ms, double *gather_ms, double *download_ms);
+/* Which RCCL this group has loaded: "<path of the library>, ncclGetVersion <code>, <n> communicator(s)"; empty while none is loaded. */
+int sp_group_rccl_info(const sp_group *group, char *text, size_t capacity);
 /* Device bytes the root member holds for the gather beyond its own strip (image + staging), after the last render. */
 int sp_group_root_bytes(const sp_group *group, size_t *image_bytes, size_t *staging_bytes);
 const char *sp_group_last_error(const sp_group *group);

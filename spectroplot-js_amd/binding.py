@@ -125,6 +125,8 @@ class Library:
             L.sp_group_transport_note.argtypes = [vp]
             L.sp_group_last_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
             L.sp_group_root_bytes.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+            if hasattr(L, "sp_group_rccl_info"):
+                L.sp_group_rccl_info.argtypes = [vp, C.c_char_p, sz]
             L.sp_render_strip.argtypes = [vp, C.POINTER(_Request), vp, sz, i32, C.POINTER(_Reply), i32]
         if hasattr(L, "sp_context_last_upload_bytes"):
             L.sp_context_last_upload_bytes.argtypes = [vp, C.POINTER(sz)]
@@ -403,6 +405,12 @@ class Group:
     def transport_note(self):
         """Why the last transport was chosen when it was not the first choice (RCCL failures, peer access that could not be enabled)."""
         return self.lib.L.sp_group_transport_note(self.h).decode()
+
+    def rccl_info(self):
+        """Which RCCL the group has loaded (library path, version code, communicators); '' while none is."""
+        buf = C.create_string_buffer(512)
+        self.lib.L.sp_group_rccl_info(self.h, buf, len(buf))
+        return buf.value.decode()
 
     def timings(self):
         """Milliseconds of the last render's phases: (upload + render of the slowest member, gather on the root, download)."""

@@ -16,6 +16,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -40,6 +41,7 @@ struct Rccl {
     int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
     int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
     bool load(const char *override_name)
     {
         if (lib) return true;
@@ -64,6 +66,11 @@ struct Rccl {
         Send = (decltype(Send))dlsym(lib, "ncclSend");
         Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
+        {
+            Dl_info di;   // where the loader found it
+            if (CommInitAll && dladdr((void *)CommInitAll, &di) && di.dli_fname) loaded_from = di.dli_fname;
+        }
         if (CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv) return true;
         why = loaded_from + " lacks an entry point of the gather (ncclCommInitAll / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd)";
         dlclose(lib);
@@ -356,6 +363,19 @@ extern "C" const char *sp_group_transport(const sp_group *g)
 }
 
 extern "C" const char *sp_group_transport_note(const sp_group *g) { return g ? g->note.c_str() : ""; }
+
+extern "C" int sp_group_rccl_info(const sp_group *g, char *text, size_t capacity)
+{
+    if (!g || !text || !capacity) return SP_ERR_INVALID_ARG;
+    std::string t;
+    if (g->rccl.lib) {
+        int v = 0;
+        if (g->rccl.GetVersion) (void)g->rccl.GetVersion(&v);
+        t = g->rccl.loaded_from + ", ncclGetVersion " + std::to_string(v) + ", " + std::to_string(g->comms.size()) + " communicator(s)";
+    }
+    snprintf(text, capacity, "%s", t.c_str());
+    return SP_OK;
+}
 
 extern "C" int sp_group_last_timings(const sp_group *g, double *render_ms, double *gather_ms, double *download_ms)
 {

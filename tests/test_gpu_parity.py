@@ -184,6 +184,9 @@ def test_group_forced_rccl_moves_the_roots_strip_through_a_self_exchange(pkg, go
     g = pkg.Group([0])
     _check_group_against_merged_vectors(pkg, golden, g, 1, "device", "rccl")
     assert g.transport_note() == "", g.transport_note()
+    info = g.rccl_info()               # e.g. "/opt/rocm/lib/librccl.so.1, ncclGetVersion 22707, 1 communicator(s)"
+    print("RCCL in use:", info)
+    assert "rccl" in info.lower() and "1 communicator" in info and int(info.split("ncclGetVersion ")[1].split(",")[0]) >= 20000, info
     image_bytes, staging_bytes = g.root_bytes()
     assert staging_bytes > 0          # the spectrogram layout's strip arrived beside the image
     g.close()
