@@ -163,6 +163,17 @@ int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes
  * overrides how many chunks of frames a large request is pipelined in (default 4, 8 or 16 by size).
  */
 int sp_context_last_upload_bytes(const sp_context *ctx, size_t *nbytes);
+/*
+ * (tests) The upload plan sp_render would follow for a request of this shape, without a device: how [0, width) is cut into chunks of
+ * frames and, for a sparse request, the packed layout and the pitched copies of every chunk.  out[] receives int64 words: packed (0 / 1),
+ * chunks, device bytes, link bytes; per chunk x0, x1 and, if packed: the capture's sample where frame x0 starts, the samples between
+ * source rows (floor(stride)) and between device rows, the chunk's byte offset on the device, the kernel's position of frames x0 and
+ * x1 - 1, the bit pattern of the kernel's stride, the number of pitched copies, then first row, end row, smallest and largest drift
+ * per copy.  *used = words needed (SP_ERR_INVALID_ARG if capacity is smaller).  tests/test_upload_plan_cpu.py checks every frame of
+ * thousands of shapes against the reference's own positions (lib/worker.js:72).
+ */
+int sp_debug_upload_plan(int32_t format, int32_t n, size_t nbytes, int32_t width, int32_t want_image, int64_t *out, size_t capacity,
+                         size_t *used);
 
 /*
  * The same with the request given by names, as the reference's caller assembles its message from options

@@ -1084,6 +1084,91 @@ static hipError_t upload_packed_chunk(const PackedChunk &ch, int n, int sample_w
     return e;
 }
 
+// How [0, width) is cut into chunks of frames for a request that moves in_est bytes of samples in and rgba_bytes of image out.
+static void chunk_bounds(int32_t width, size_t in_est, size_t rgba_bytes, bool chunkable, std::vector<int32_t> &bounds)
+{
+    int chunks = 1;
+    // SPECTROPLOT_HIP_RENDER_CHUNKS=k overrides the count (2 .. 16), SPECTROPLOT_HIP_CHUNK_RATIO=r the size of a chunk relative to
+    // its neighbour (0.2 .. 1; 1 = equal chunks); both read once
+    static const int env_chunks = getenv("SPECTROPLOT_HIP_RENDER_CHUNKS") ? atoi(getenv("SPECTROPLOT_HIP_RENDER_CHUNKS")) : 0;
+    static const double env_ratio = getenv("SPECTROPLOT_HIP_CHUNK_RATIO") ? atof(getenv("SPECTROPLOT_HIP_CHUNK_RATIO")) : 0.0;
+    const double ratio = env_ratio >= 0.2 && env_ratio <= 1.0 ? env_ratio : 0.65;
+    const bool uneven = ratio < 1.0;
+    if (chunkable && width >= 1024 && in_est + rgba_bytes >= ((size_t)16 << 20)) {
+        chunks = in_est + rgba_bytes >= ((size_t)64 << 20) ? 6 : 4;
+        if (env_chunks >= 2 && env_chunks <= sp_context::kMaxChunks && width >= 32 * env_chunks) chunks = env_chunks;
+    }
+    // The busier direction of the link never pauses; what does not overlap it is one chunk's way in the other direction plus its
+    // render: the LAST chunk's image when the samples are the longer transfer, the FIRST chunk's samples when the image is.  So the
+    // chunks shrink (or grow) geometrically towards that end - each 0.65 of its neighbour, which also keeps the shorter direction
+    // from falling behind - instead of being equal (measured, config 2: 8 equal chunks 2.73 ms, pure two-way copy 2.37 ms; every
+    // additional copy call costs the link ~13 us, so few chunks).  Chunks end on multiples of 32 frames.
+    bounds.assign(1, 0);
+    if (chunks > 1 && uneven) {
+        const bool in_heavy = in_est >= rgba_bytes;
+        double w[sp_context::kMaxChunks], sum = 0, acc = 0;
+        for (int k = 0; k < chunks; k++) sum += (w[k] = std::pow(ratio, in_heavy ? k : chunks - 1 - k));
+        for (int k = 0; k + 1 < chunks; k++) {
+            acc += w[k];
+            const int32_t x = (int32_t)((int64_t)((double)width * acc / sum) & ~(int64_t)31);
+            if (x > bounds.back() && x < width) bounds.push_back(x);
+        }
+        bounds.push_back(width);
+    } else {
+        for (int k = 0; k < chunks; k++) {
+            const int32_t x = k + 1 == chunks ? width : (int32_t)(((int64_t)width * (k + 1) / chunks) & ~(int64_t)31);
+            if (x > bounds.back()) bounds.push_back(x);
+        }
+        if (bounds.back() != width) bounds.push_back(width);
+    }
+    if (bounds.size() < 2) bounds.push_back(width);   // (width = 0: one empty chunk, so that the reply still gets its initial values)
+}
+
+// (tests) The upload plan sp_render would use for a request of this shape - pure host arithmetic, no device.  out[]: packed (0 / 1),
+// chunks, device bytes, link bytes; per chunk x0, x1 and, if packed, first, F, P, dev_off, pos2_x0, pos2_last, the bits of stride2,
+// blocks, then j0, j1, dmin, dmax per block.
+extern "C" int sp_debug_upload_plan(int32_t format, int32_t n, size_t nbytes, int32_t width, int32_t want_image, int64_t *out, size_t capacity,
+                                    size_t *used)
+{
+    if (format < 0 || format >= SP_FMT_COUNT || n < 2 || width < 1 || !out || !used) return SP_ERR_INVALID_ARG;
+    const spfmt::Format f = spfmt::describe(format);
+    const double sample_count = (double)nbytes / (double)f.width;
+    const double stride = width > 1 ? (sample_count - (double)n) / (double)(width - 1) : 0.0;
+    const bool stride_ok = stride >= 0.0 && std::isfinite(stride) && 0.5 + stride * (double)(width - 1) < 2147483000.0;
+    const size_t rgba_bytes = 4 * (size_t)width * (size_t)n;
+    bool sparse = stride_ok && width >= 2 && stride > (double)n
+                  && (size_t)(spjs::to_int32(0.5 + stride * (double)(width - 1)) + (int64_t)n) * (size_t)f.width <= nbytes;
+    std::vector<PackedChunk> packed;
+    std::vector<int32_t> bounds;
+    size_t dev = 0, link = nbytes;
+    for (int attempt = sparse ? 0 : 1; attempt < 2; attempt++) {
+        chunk_bounds(width, attempt == 0 ? (size_t)width * (size_t)n * (size_t)f.width : nbytes, rgba_bytes, want_image && stride_ok, bounds);
+        if (attempt == 0) {
+            sparse = build_packed_chunks(n, f.width, nbytes, width, stride, bounds, packed, &dev, &link) && packed.size() + 1 == bounds.size();
+            if (sparse) break;
+            packed.clear();
+            dev = 0;
+            link = nbytes;
+        }
+    }
+    std::vector<int64_t> v{sparse ? 1 : 0, (int64_t)bounds.size() - 1, (int64_t)dev, (int64_t)link};
+    for (size_t c = 0; c + 1 < bounds.size(); c++) {
+        v.push_back(bounds[c]);
+        v.push_back(bounds[c + 1]);
+        if (!sparse) continue;
+        const PackedChunk &ch = packed[c];
+        int64_t bits;
+        memcpy(&bits, &ch.stride2, 8);
+        for (int64_t x : {ch.first, ch.F, ch.P, (int64_t)ch.dev_off, ch.pos2_x0, ch.pos2_last, bits, (int64_t)ch.blocks.size()}) v.push_back(x);
+        for (const PackedBlock &b : ch.blocks)
+            for (int64_t x : {(int64_t)b.j0, (int64_t)b.j1, (int64_t)b.dmin, (int64_t)b.dmax}) v.push_back(x);
+    }
+    *used = v.size();
+    if (v.size() > capacity) return SP_ERR_INVALID_ARG;
+    memcpy(out, v.data(), v.size() * 8);
+    return SP_OK;
+}
+
 // sp_render / sp_render_strip: `image_width` is the width in frames of the image reply->rgba points into (the strip's own width for
 // sp_render); it only matters for the spectrogram layout, whose rows are image_width pixels apart.
 static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
@@ -1149,37 +1234,8 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
     size_t packed_dev_bytes = 0, packed_link_bytes = 0;
     for (int attempt = sparse ? 0 : 1; attempt < 2; attempt++) {
         const size_t in_est = attempt == 0 ? W * n * (size_t)f.width : nbytes;
-        chunks = 1;
-        // SPECTROPLOT_HIP_RENDER_CHUNKS=k overrides the count (2 .. 16), SPECTROPLOT_HIP_CHUNK_RATIO=r the size of a chunk relative to
-        // its neighbour (0.2 .. 1; 1 = equal chunks); both read once
-        static const int env_chunks = getenv("SPECTROPLOT_HIP_RENDER_CHUNKS") ? atoi(getenv("SPECTROPLOT_HIP_RENDER_CHUNKS")) : 0;
-        static const double env_ratio = getenv("SPECTROPLOT_HIP_CHUNK_RATIO") ? atof(getenv("SPECTROPLOT_HIP_CHUNK_RATIO")) : 0.0;
-        const double ratio = env_ratio >= 0.2 && env_ratio <= 1.0 ? env_ratio : 0.65;
-        const bool uneven = ratio < 1.0;
-        if (reply->rgba && width >= 1024 && in_est + rgba_bytes >= ((size_t)16 << 20) && stride_ok) {
-            chunks = in_est + rgba_bytes >= ((size_t)64 << 20) ? 6 : 4;
-            if (env_chunks >= 2 && env_chunks <= sp_context::kMaxChunks && width >= 32 * env_chunks) chunks = env_chunks;
-        }
-        // The busier direction of the link never pauses; what does not overlap it is one chunk's way in the other direction plus its
-        // render: the LAST chunk's image when the samples are the longer transfer, the FIRST chunk's samples when the image is.  So the
-        // chunks shrink (or grow) geometrically towards that end - each 0.65 of its neighbour, which also keeps the shorter direction
-        // from falling behind - instead of being equal (measured, config 2: 8 equal chunks 2.73 ms, pure two-way copy 2.37 ms; every
-        // additional copy call costs the link ~13 us, so few chunks).  Chunks end on multiples of 32 frames.
-        bounds.assign(1, 0);
-        if (chunks > 1 && uneven) {
-            const bool in_heavy = in_est >= rgba_bytes;
-            double w[sp_context::kMaxChunks], sum = 0, acc = 0;
-            for (int k = 0; k < chunks; k++) sum += (w[k] = std::pow(ratio, in_heavy ? k : chunks - 1 - k));
-            for (int k = 0; k + 1 < chunks; k++) {
-                acc += w[k];
-                const int32_t x = (int32_t)((int64_t)((double)width * acc / sum) & ~(int64_t)31);
-                if (x > bounds.back() && x < width) bounds.push_back(x);
-            }
-            bounds.push_back(width);
-            chunks = (int)bounds.size() - 1;
-        } else {
-            for (int k = 0; k < chunks; k++) bounds.push_back(k + 1 == chunks ? width : (int32_t)(((int64_t)width * (k + 1) / chunks) & ~(int64_t)31));
-        }
+        chunk_bounds(width, in_est, rgba_bytes, reply->rgba != nullptr && stride_ok, bounds);
+        chunks = (int)bounds.size() - 1;
         if (attempt == 0) {
             sparse = build_packed_chunks(req->n, f.width, nbytes, width, stride, bounds, packed, &packed_dev_bytes, &packed_link_bytes)
                      && (int)packed.size() == chunks;
