@@ -56,6 +56,23 @@ def load_cmap(name):
     return lut
 
 
+def host_cpu_model():
+    """The host CPU's model string and socket count (BASELINE.md section 3 asks for the CPU the baseline ran on)."""
+    try:
+        names, sockets = [], set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                names.append(line.split(":", 1)[1].strip())
+            elif line.startswith("physical id"):
+                sockets.add(line.split(":", 1)[1].strip())
+        if names:
+            return "%s x %d socket(s)" % (names[0], max(len(sockets), 1))
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(fmt, n, window, seconds=8.0):
     """Times the JavaScript oracle (bit-exact restatement of the reference worker, incl. its fft_nayuki radix-2 loop) under
     Node on this host on a bounded sample of the same workload, two legs: one thread, and one
@@ -63,6 +80,7 @@ def cpu_baseline(fmt, n, window, seconds=8.0):
     (lib/spectroplot.js:87).  `value` is the all-cores figure; the one-thread figure is reported beside it."""
     script = os.path.join(ROOT, "oracle", "js", "cpu_baseline.js")
     cores = os.cpu_count() or 1
+    model = host_cpu_model()
 
     def leg(log2_s, threads):
         out = subprocess.run(["node", script, fmt, str(log2_s), str(n), window, str(seconds), str(threads)], capture_output=True, text=True,
@@ -71,12 +89,12 @@ def cpu_baseline(fmt, n, window, seconds=8.0):
 
     try:
         one = leg(22, 1)
-        res = {"value": one["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "oracle/js/worker_oracle.js under node %s: 2^22 samples of the same synthetic %s signal, n=%d, %s, %d renders in %.1f s "
-                         "on 1 thread of %d host cores" % (one["node"], fmt, n, window, one["reps"], one["seconds"], cores),
+        res = {"value": one["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": model, "node": one["node"],
+               "sample": "oracle/js/worker_oracle.js under node %s on %s: 2^22 samples of the same synthetic %s signal, n=%d, %s, %d renders in "
+                         "%.1f s on 1 thread of %d host cores" % (one["node"], model, fmt, n, window, one["reps"], one["seconds"], cores),
                "msamples_per_s": one["msamples_per_s"], "one_thread": {"frames_per_s": one["frames_per_s"], "msamples_per_s": one["msamples_per_s"]}}
     except Exception as e:  # the baseline is reported, never required
-        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": model, "sample": "failed: %r" % (e,)}
     try:
         if cores > 1:
             allc = leg(20, cores)
@@ -150,7 +168,8 @@ def rocprof_kernel_us(argv_config):
         try:
             for line in open(child_out):
                 if line.startswith("{") and '"ms_per_step"' in line:
-                    child_ms = json.loads(line)["ms_per_step"]
+                    j = json.loads(line)
+                    child_ms = j.get("ms_per_step_steady", j["ms_per_step"])   # (the launches the average is over are mostly steady ones)
         except Exception:
             child_ms = None
         best = None
@@ -274,7 +293,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps before the timed ones (default: the clock spin-up of the configuration + 200; `value` is ALWAYS "
+                         "--steps steps right after --warmup steps of the fresh process, nothing in between)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="(default when N > 1) also time the RCCL gather of the RGBA strips to rank 0")
@@ -416,46 +437,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Clock spin-up (untimed, before the W warm-up steps): an idle MI355X runs its first few hundred launches ~5-15 % slower
-    # while the shader clock ramps, so a short --warmup would time the ramp instead of the kernel.
-    # A fixed count (every rank runs the same collectives): ~0.3 s at config 2, scaled down for the larger configs.
-    spinup = 0 if args.warmup >= 1000 else max(50, int(3000 * 16384 / max(W, 16384) * 1024 / n) if n <= 1024 else 200)
-    # what a caller sees before any of that (reported, never the headline): the very first step of this process (kernel code upload,
-    # cold caches, idle clocks) and the 20 steps right after it
+    # `value` = --steps steps right after --warmup steps of this fresh process: nothing else sits between the two.  An idle MI355X runs
+    # its first few hundred launches ~5-15 % slower while the shader clock ramps, so the DEFAULT warm-up is that
+    # spin-up (~0.3 s at config 2, scaled down for the larger configs) + 200; a caller who passes a short --warmup gets the figure that
+    # warm-up gives (the driver's `--steps 20 --warmup 5` times the ramp) and the steady figure beside it as `value_steady`.
+    spinup = max(50, int(3000 * 16384 / max(W, 16384) * 1024 / n) if n <= 1024 else 200)
+    warmup_given = args.warmup is not None
+    if not warmup_given:
+        args.warmup = spinup + 200
+    # the warm-up steps, the first ones of them on the clock (reported as `cold`, never the headline): the very first step of this
+    # process (kernel code upload, cold caches, idle clocks) and up to 20 steps right after it
+    done = 0
+    cold = {"first_step_ms": None, "next_steps": 0, "ms_per_step_next": None}
     torch.cuda.synchronize()
-    tc = time.perf_counter()
-    step()
-    finish_pending()
-    torch.cuda.synchronize()
-    first_step_ms = (time.perf_counter() - tc) * 1e3
-    tc = time.perf_counter()
-    for _ in range(20):
+    if args.warmup >= 1:
+        tc = time.perf_counter()
         step()
-    finish_pending()
-    torch.cuda.synchronize()
-    cold = {"first_step_ms": first_step_ms, "ms_per_step_next_20": (time.perf_counter() - tc) * 1e3 / 20}
-    # ... and --steps steps right after --warmup steps with NO clock spin-up in between (the 21 steps above count as warm-up; a longer
-    # --warmup is completed first): what the headline would be without the spin-up below.  Barrier, synchronise, maximum over ranks as
-    # for the headline.
-    for _ in range(max(0, args.warmup - 21)):
-        step()
-    finish_pending()
-    sync()
-    tw = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    finish_pending()
-    sync()
-    dt_warm = time.perf_counter() - tw
-    if dist is not None:
-        t = torch.tensor([dt_warm], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_warm = float(t.item())
-    for _ in range(spinup):
-        step()
-    finish_pending()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
+        finish_pending()
+        torch.cuda.synchronize()
+        cold["first_step_ms"] = (time.perf_counter() - tc) * 1e3
+        done = 1
+    k = min(20, args.warmup - done)
+    if k > 0:
+        tc = time.perf_counter()
+        for _ in range(k):
+            step()
+        finish_pending()
+        torch.cuda.synchronize()
+        cold.update({"next_steps": k, "ms_per_step_next": (time.perf_counter() - tc) * 1e3 / k})
+        done += k
+    for _ in range(args.warmup - done):
         step()
     finish_pending()
     sync()
@@ -465,12 +476,30 @@ def main():
     finish_pending()                                          # the last render's merge belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
-    final = batcher.final_record()
-    hsum = int(final[:L].sum().item())                        # all slices after the merge
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the steady figure (an extra): where the warm-up was shorter than the spin-up, the same --steps again after the rest of it
+    dt_steady, steady_after = dt, args.warmup
+    if args.warmup < spinup:
+        for _ in range(spinup + 200 - args.warmup):
+            step()
+        finish_pending()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish_pending()
+        sync()
+        dt_steady = time.perf_counter() - t0
+        steady_after = spinup + 200 + args.steps
+        if dist is not None:
+            t = torch.tensor([dt_steady], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_steady = float(t.item())
+    final = batcher.final_record()
+    hsum = int(final[:L].sum().item())                        # all slices after the merge
 
     # dominant kernel: live HIP-event timing of the frame-loop kernel on its stream, outside the timed region
     ctx.enable_timing(True)
@@ -543,7 +572,7 @@ def main():
                             "verdict": ("kernel duration " + ("within 2 %" if abs(ratio - 1) <= 0.02 else "differs by more than 2 %")
                                         + " (ratio %.3f); back-to-back steps %.1f %% %s over the rotating sets" % (ratio, abs(step_ratio - 1) * 100,
                                                                                                              "slower" if step_ratio > 1 else "faster")
-                                        + ("" if abs(step_ratio - 1) <= 0.02 and abs(ratio - 1) <= 0.02 else
+                                        + ("" if step_ratio <= 1.02 and ratio <= 1.02 else
                                            ": the default figure leans on the Infinity Cache (the one-set image's stores never have to reach HBM); "
                                            "`python bench.py --rotate-all` measures the whole line on the rotating sets"))}
                 del ins, outs
@@ -657,17 +686,21 @@ def main():
     # verdict says so), the fraction to quote is the one over sets that stream through HBM; the one-set figure stays beside it.
     frac_one_set = achieved / 8000.0
     achieved_rot = (algo_bytes / (rotating["kernel_ms_rotating"] * 1e-3) / 1e9) if rotating and rotating.get("kernel_ms_rotating") else None
-    leans = bool(achieved_rot) and (abs(rotating["ratio"] - 1) > 0.02 or abs(rotating["step_ratio"] - 1) > 0.02) and not rot_sets
+    # (only a SLOWER rotating leg switches the headline: a rotating leg that measures faster is noise, not a reason to quote the higher figure)
+    leans = bool(achieved_rot) and (rotating["ratio"] > 1.02 or rotating["step_ratio"] > 1.02) and not rot_sets
     achieved_head = achieved_rot if leans else achieved
     if rank == 0:
         out = {
             "metric": "STFT frames/sec (N=1024 cf32) + IQ MSamples/s end-to-end to RGBA" if args.config == "cfg2"
                       else "STFT frames/sec (%s)" % desc,
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "spinup_steps_untimed": spinup, "cold": cold,
-            "value_after_driver_warmup": world * W * args.steps / dt_warm, "ms_per_step_after_driver_warmup": dt_warm / args.steps * 1e3,
-            "value_after_driver_warmup_note": "--steps steps right after max(--warmup, 21) steps of a fresh process, no clock spin-up before them; "
-                                              "`value` follows spinup_steps_untimed further launches and --warmup more",
+            "ms_per_step": dt / args.steps * 1e3, "cold": cold,
+            "value_is": "--steps steps right after --warmup steps of a fresh process (%s --warmup %d), nothing in between"
+                        % ("the caller's" if warmup_given else "default", args.warmup),
+            "value_steady": world * W * args.steps / dt_steady, "ms_per_step_steady": dt_steady / args.steps * 1e3,
+            "value_steady_note": ("the same --steps steps again once the process had run %d steps (the clock spin-up of this configuration: "
+                                  "%d steps + 200): the shader clock no longer ramps" % (steady_after, spinup)) if dt_steady is not dt
+                                 else "the warm-up covered the clock spin-up of this configuration (%d steps): value_steady is value" % spinup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + ", gain 6, range 30, spectrogram layout, %d frames per GPU" % W + (", L/R split (channelMode)" if args.channel_mode else "")

@@ -19,6 +19,8 @@
  *   sp_render                lib/worker.js:23-156       renderFft(ctx) on host buffers = one postMessage -> one reply
  *   sp_render_strip          lib/worker.js:23-156 + lib/spectroplot.js:1241-1244   the same, written into the strip's band of the caller's image
  *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
+ *   sp_plan_execute_from_host  lib/worker.js:68-137     the same with the capture in host memory (uploaded in chunks under the renders),
+ *                                                        outputs resident in HBM: what a group member does with its slice
  *   sp_merge_replies         lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
  *   sp_place_strips          lib/spectroplot.js:1241-1244   the caller's putImageData of every slice's strip, on the device
  *   sp_group_render          lib/spectroplot.js:1206-1244, lib/samples.js:253-258   the caller's sliced render: one slice per device, the
@@ -159,8 +161,11 @@ int sp_render_strip(sp_context *ctx, const sp_request *req, const uint8_t *bytes
  * Bytes of samples the last sp_render / sp_render_strip / sp_render_named on this context sent over the host link.  A request whose
  * frames are more than n samples apart (stride > n, lib/worker.js:50: the reference's loop skips the samples in between, :70-75) and lie
  * inside the capture uploads the frames' own samples only, as rows of pitched copies into a packed device buffer; every other request
- * uploads the capture as it is.  SPECTROPLOT_HIP_NO_PACKED_UPLOAD=1 turns the packed upload off; SPECTROPLOT_HIP_RENDER_CHUNKS=2..16
- * overrides how many chunks of frames a large request is pipelined in (default 4, 8 or 16 by size).
+ * uploads the capture as it is.  SPECTROPLOT_HIP_NO_PACKED_UPLOAD=1 turns the packed upload off.
+ * A large request (>= 16 MiB of samples + image, width >= 1024) is pipelined in chunks of frames: 4, from 64 MiB 6, of UNEVEN size -
+ * each 0.65 of its neighbour, shrinking towards the end of the longer transfer's direction.  SPECTROPLOT_HIP_RENDER_CHUNKS=2..16
+ * overrides the count and SPECTROPLOT_HIP_CHUNK_RATIO=0.2..1 the ratio (1 = equal chunks); both are read once per process and neither
+ * applies below that gate (the count also needs width >= 32 per chunk).
  */
 int sp_context_last_upload_bytes(const sp_context *ctx, size_t *nbytes);
 /*
@@ -219,6 +224,13 @@ void sp_plan_destroy(sp_plan *plan);
  * bounded - a launch that never sees the number traps instead of hanging.)
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
+/*
+ * The same request with the capture in HOST memory and the reply in DEVICE memory: the samples travel in chunks of frames on a copy
+ * stream of the context while earlier chunks are rendered (the chunk schedule of sp_render; a sparse request uploads only the samples
+ * its frames read), nothing comes back.  Returns once everything is queued: `bytes` must stay valid, and the reply is complete, when
+ * the context's stream has been synchronised (page-locked `bytes`: the copies are asynchronous and at link rate).
+ */
+int sp_plan_execute_from_host(sp_plan *plan, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
 /*
  * The caller's merge of slice replies (lib/spectroplot.js:1229-1238) on device-resident side outputs: `count` records of
  * [c_hist u64[lut_len] | cB_hist u64[SP_CB_HIST_SIZE] | dBfs_min f64 | dBfs_max f64] laid end to end at d_records (what an

@@ -1169,54 +1169,44 @@ extern "C" int sp_debug_upload_plan(int32_t format, int32_t n, size_t nbytes, in
     return SP_OK;
 }
 
-// sp_render / sp_render_strip: `image_width` is the width in frames of the image reply->rgba points into (the strip's own width for
+// sp_render / sp_render_strip / sp_plan_execute_from_host: the capture comes from HOST memory, in chunks of frames that travel while
+// earlier chunks are rendered.  `image_width` is the width in frames of the image reply->rgba points into (the strip's own width for
 // sp_render); it only matters for the spectrogram layout, whose rows are image_width pixels apart.
-static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
-                       int32_t image_width)
+// device_out = false: the reply's pointers are host pointers; the image travels back chunk by chunk, the small outputs in one copy, and
+// the call returns when everything has arrived.  device_out = true: the reply's pointers are device pointers (as for sp_plan_execute);
+// nothing comes back, and the call returns once everything is queued.
+static int render_core(sp_plan *plan, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply, int32_t image_width,
+                       bool device_out)
 {
-    if (!ctx || !reply) return SP_ERR_INVALID_ARG;
-    int rc = validate_request(ctx, req);
-    if (rc) return rc;
-    if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
-    if (image_width < width) return fail(ctx, SP_ERR_INVALID_ARG, "image_width < width");
-    if (nbytes && !bytes) return fail(ctx, SP_ERR_INVALID_ARG, "bytes is null");
-    // the reference constructs its typed view before anything else (worker.js:24)
-    if (nbytes % (size_t)spfmt::describe(req->format).elem)
-        return fail(ctx, SP_ERR_BYTE_LENGTH, "byte length is not a multiple of the element size");
-    SP_HIP(ctx, hipSetDevice(ctx->device));
-
-    if (!ctx->cached_plan || !same_request(ctx->cached_plan, req)) {
-        if (ctx->cached_plan) sp_plan_destroy(ctx->cached_plan);
-        ctx->cached_plan = nullptr;
-        rc = sp_plan_create(ctx, req, &ctx->cached_plan);
-        if (rc) return rc;
-    }
-    sp_plan *plan = ctx->cached_plan;
+    sp_context *ctx = plan->ctx;
+    const sp_request *req = &plan->req;
     hipStream_t s = ctx->stream;
 
     const size_t W = (size_t)width, n = (size_t)req->n, L = (size_t)req->lut_len;
     const size_t rgba_bytes = 4 * W * n;
     const size_t host_pitch = req->waterfall ? 4 * n : 4 * (size_t)image_width;   // bytes between rows of the caller's image
-    rc = ctx->out_rgba.reserve(rgba_bytes + 16);
+    int rc = SP_OK;
     // small outputs: [c_hist L u64][cb_hist 1000 u64][minmax 2 f64][gauges 3*W u8]
     const size_t small_u64 = L + SP_CB_HIST_SIZE + 2;
     DeviceBuffer &small = ctx->render_small;
     const size_t small_bytes = small_u64 * 8 + 3 * W;
-    if (!rc) rc = small.reserve(small_bytes + 16);
-    if (!rc) rc = ctx->host_small.reserve(small_bytes + 16);
-    if (rc) return fail(ctx, rc, "sp_render: out of memory");
-    uint64_t *d_c = (uint64_t *)small.p, *d_cb = d_c + L;
-    double *d_mm = (double *)(d_cb + SP_CB_HIST_SIZE);
-    uint8_t *d_g = (uint8_t *)(d_mm + 2);
-
-    sp_reply d{};
-    d.rgba = reply->rgba ? (uint8_t *)ctx->out_rgba.p : nullptr;
-    d.gauge_mins = d_g;
-    d.gauge_maxs = d_g + W;
-    d.gauge_amps = d_g + 2 * W;
-    d.c_hist = d_c;
-    d.cb_hist = d_cb;
-    d.dbfs_minmax = d_mm;
+    sp_reply d = *reply;
+    if (!device_out) {
+        rc = ctx->out_rgba.reserve(rgba_bytes + 16);
+        if (!rc) rc = small.reserve(small_bytes + 16);
+        if (!rc) rc = ctx->host_small.reserve(small_bytes + 16);
+        if (rc) return fail(ctx, rc, "sp_render: out of memory");
+        uint64_t *d_c = (uint64_t *)small.p, *d_cb = d_c + L;
+        double *d_mm = (double *)(d_cb + SP_CB_HIST_SIZE);
+        uint8_t *d_g = (uint8_t *)(d_mm + 2);
+        d.rgba = reply->rgba ? (uint8_t *)ctx->out_rgba.p : nullptr;
+        d.gauge_mins = d_g;
+        d.gauge_maxs = d_g + W;
+        d.gauge_amps = d_g + 2 * W;
+        d.c_hist = d_c;
+        d.cb_hist = d_cb;
+        d.dbfs_minmax = d_mm;
+    }
 
     // Large requests are rendered in chunks of frames: chunk k's samples travel to the device while chunk k-1 is rendered and
     // chunk k-2's part of the image travels back (PCIe is full duplex; the kernels are a few per cent of the copies).  Chunks end
@@ -1234,7 +1224,8 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
     size_t packed_dev_bytes = 0, packed_link_bytes = 0;
     for (int attempt = sparse ? 0 : 1; attempt < 2; attempt++) {
         const size_t in_est = attempt == 0 ? W * n * (size_t)f.width : nbytes;
-        chunk_bounds(width, in_est, rgba_bytes, reply->rgba != nullptr && stride_ok, bounds);
+        // (device_out: no image crosses the link, so the samples are the longer transfer whatever the image weighs)
+        chunk_bounds(width, in_est, device_out ? 0 : rgba_bytes, (device_out || reply->rgba != nullptr) && stride_ok, bounds);
         chunks = (int)bounds.size() - 1;
         if (attempt == 0) {
             sparse = build_packed_chunks(req->n, f.width, nbytes, width, stride, bounds, packed, &packed_dev_bytes, &packed_link_bytes)
@@ -1253,6 +1244,12 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
         for (int k = 0; k < chunks && e == hipSuccess; k++) {
             if (!ctx->ev_arrived[k]) e = hipEventCreateWithFlags(&ctx->ev_arrived[k], hipEventDisableTiming);
             if (e == hipSuccess && !ctx->ev_rendered[k]) e = hipEventCreateWithFlags(&ctx->ev_rendered[k], hipEventDisableTiming);
+        }
+        // device_out returns without waiting: whatever the stream still holds (an earlier request reading the staging buffer, the
+        // caller's own work) comes before this request's first copy
+        if (e == hipSuccess && device_out) {
+            e = hipEventRecord(ctx->ev_rendered[0], s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_in, ctx->ev_rendered[0], 0);
         }
         if (e != hipSuccess) return hip_fail(ctx, e, "sp_render streams");
     }
@@ -1310,6 +1307,7 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
             if (e != hipSuccess) break;
             rc = plan_execute_range(plan, ctx->in_bytes.p, nbytes, width, x0, x1, k == 0, k + 1 == chunks, &d, sparse ? &ps : nullptr);
             if (rc) break;
+            if (device_out) continue;
             e = hipEventRecord(ctx->ev_rendered[k], s);
             if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_out, ctx->ev_rendered[k], 0);
             if (e != hipSuccess) break;
@@ -1333,6 +1331,7 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
             return rc ? rc : hip_fail(ctx, e, "sp_render chunk");
         }
     }
+    if (device_out) return SP_OK;
     auto down = [&](void *dst, const void *src, size_t bytes_) {
         if (dst && bytes_ && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, s);
     };
@@ -1361,9 +1360,43 @@ static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *by
     return SP_OK;
 }
 
+static int render_host(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply,
+                       int32_t image_width)
+{
+    if (!ctx || !reply) return SP_ERR_INVALID_ARG;
+    int rc = validate_request(ctx, req);
+    if (rc) return rc;
+    if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
+    if (image_width < width) return fail(ctx, SP_ERR_INVALID_ARG, "image_width < width");
+    if (nbytes && !bytes) return fail(ctx, SP_ERR_INVALID_ARG, "bytes is null");
+    // the reference constructs its typed view before anything else (worker.js:24)
+    if (nbytes % (size_t)spfmt::describe(req->format).elem)
+        return fail(ctx, SP_ERR_BYTE_LENGTH, "byte length is not a multiple of the element size");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+
+    if (!ctx->cached_plan || !same_request(ctx->cached_plan, req)) {
+        if (ctx->cached_plan) sp_plan_destroy(ctx->cached_plan);
+        ctx->cached_plan = nullptr;
+        rc = sp_plan_create(ctx, req, &ctx->cached_plan);
+        if (rc) return rc;
+    }
+    return render_core(ctx->cached_plan, bytes, nbytes, width, reply, image_width, false);
+}
+
 extern "C" int sp_render(sp_context *ctx, const sp_request *req, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *reply)
 {
     return render_host(ctx, req, bytes, nbytes, width, reply, width);
+}
+
+extern "C" int sp_plan_execute_from_host(sp_plan *plan, const uint8_t *bytes, size_t nbytes, int32_t width, const sp_reply *d_reply)
+{
+    if (!plan || !d_reply) return SP_ERR_INVALID_ARG;
+    sp_context *ctx = plan->ctx;
+    if (width < 0) return fail(ctx, SP_ERR_INVALID_ARG, "width < 0");
+    if (nbytes && !bytes) return fail(ctx, SP_ERR_INVALID_ARG, "bytes is null");
+    if (nbytes % (size_t)plan->fmt.elem) return fail(ctx, SP_ERR_BYTE_LENGTH, "byte length is not a multiple of the element size");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    return render_core(plan, bytes, nbytes, width, d_reply, width, true);
 }
 
 extern "C" int sp_context_last_upload_bytes(const sp_context *ctx, size_t *nbytes)

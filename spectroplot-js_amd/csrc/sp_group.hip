@@ -71,8 +71,10 @@ struct Rccl {
             Dl_info di;   // where the loader found it
             if (CommInitAll && dladdr((void *)CommInitAll, &di) && di.dli_fname) loaded_from = di.dli_fname;
         }
-        if (CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv) return true;
-        why = loaded_from + " lacks an entry point of the gather (ncclCommInitAll / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd)";
+        // (ncclCommAbort is part of the set: without it a half-posted exchange could not be taken back, and giving up on RCCL would
+        // have to wait for kernels that may never finish)
+        if (CommInitAll && CommDestroy && CommAbort && GroupStart && GroupEnd && Send && Recv) return true;
+        why = loaded_from + " lacks an entry point of the gather (ncclCommInitAll / ncclCommAbort / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd)";
         dlclose(lib);
         lib = nullptr;
         return false;
@@ -109,7 +111,7 @@ struct Member {
     hipStream_t stream = nullptr;
     hipEvent_t started = nullptr, rendered = nullptr, done = nullptr;
     sp_plan *plan = nullptr;
-    DevBuf in, strip, small;
+    DevBuf strip, small;
     int status = SP_OK;
     std::string error;
     // host mode: the slice's side outputs and the host clock of its render
@@ -194,8 +196,7 @@ void give_up_rccl(sp_group *g, const std::string &why)
 {
     for (void *c : g->comms)
         if (c) {
-            if (g->rccl.CommAbort) (void)g->rccl.CommAbort(c);
-            else if (g->rccl.CommDestroy) (void)g->rccl.CommDestroy(c);
+            (void)g->rccl.CommAbort(c);
         }
     g->comms.clear();
     g->rccl_state = kRcclFailed;
@@ -305,6 +306,12 @@ extern "C" int sp_group_create(const int32_t *devices, int32_t count, sp_group *
             }
         }
         (void)hipSetDevice(root);
+        // (tests) treat every other member as one the root cannot address: its strip is staged beside the image and re-tiled
+        const char *np = getenv("SPECTROPLOT_HIP_ASSUME_NO_PEER");
+        if (np && *np && strcmp(np, "0") != 0) {
+            for (int i = 1; i < count; i++) g->m[(size_t)i].peer_ok = false;
+            add_note(g, "SPECTROPLOT_HIP_ASSUME_NO_PEER: copies to the root go through a staging block");
+        }
     }
     if (rc != SP_OK) {
         sp_group_destroy(g);
@@ -337,7 +344,6 @@ extern "C" void sp_group_destroy(sp_group *g)
     }
     for (Member &mb : g->m) {
         (void)hipSetDevice(mb.device);
-        mb.in.release();
         mb.strip.release();
         mb.small.release();
         if (mb.ctx) {
@@ -527,7 +533,6 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
         hip(hipSetDevice(mb.device), "hipSetDevice");
         if (mb.status) return;
         hip(hipEventRecord(mb.started, mb.stream), "hipEventRecord");
-        if (b1 > b0) hip(hipMemcpyAsync(mb.in.p, bytes + b0, b1 - b0, hipMemcpyHostToDevice, mb.stream), "slice upload");
         if (mb.status) return;
         uint64_t *d_c = (uint64_t *)mb.small.p;
         uint8_t *d_g = (uint8_t *)(d_c + rec_u64);
@@ -539,7 +544,8 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
         d.gauge_mins = d_g;
         d.gauge_maxs = d_g + sw;
         d.gauge_amps = d_g + 2 * sw;
-        const int rc = sp_plan_execute(mb.plan, mb.in.p, b1 - b0, (int32_t)sw, &d);
+        // the slice travels in chunks of frames while earlier chunks are rendered (a sparse slice: only the samples its frames read)
+        const int rc = sp_plan_execute_from_host(mb.plan, bytes + b0, b1 - b0, (int32_t)sw, &d);
         if (rc) {
             mb.status = rc;
             mb.error = sp_last_error(mb.ctx);
@@ -548,14 +554,11 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
         hip(hipEventRecord(mb.rendered, mb.stream), "hipEventRecord");
     };
     // (buffers first, on this thread: growing one frees the old block, and hipFree waits for the whole device - not something to do
-    // next to another member's copy in flight)
+    // next to another member's copy in flight; the capture's own staging buffer belongs to the member's context)
     for (int r = 0; r < count; r++) {
         Member &mb = g->m[(size_t)r];
-        size_t b0 = 0, b1 = 0;
-        sp_slice_bounds(nbytes, f.width, r, count, &b0, &b1);
         if (hipSetDevice(mb.device) != hipSuccess) return gfail(g, SP_ERR_HIP, "hipSetDevice");
-        int rc = mb.in.reserve(b1 - b0 + 16);
-        if (!rc) rc = mb.strip.reserve(strip_bytes + 16);
+        int rc = mb.strip.reserve(strip_bytes + 16);
         if (!rc) rc = mb.small.reserve(small_pitch);
         if (rc) return gfail(g, rc, "group member: out of device memory");
     }
@@ -578,9 +581,9 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
         }
         use_rccl = g->rccl_state == kRcclReady;
     }
-    // under RCCL the root is a sender like every other member only when the transport is forced (a one-member group has nothing else
-    // to send); normally its strip is already where the merge happens
-    const int first_sender = use_rccl && g->force_rccl ? 0 : 1;
+    // under RCCL the root is a sender like every other member only in a forced one-member group (which has nothing else to send);
+    // otherwise its strip is already where the merge happens
+    const int first_sender = use_rccl && g->force_rccl && count == 1 ? 0 : 1;
     // spectrogram strips are column bands: an RCCL receive is contiguous, so those strips land beside the image and are re-tiled;
     // peers that cannot address the root's memory directly need the same block
     bool stage = use_rccl && !req->waterfall;

@@ -30,6 +30,21 @@ def test_header_symbols_are_exported(pkg):
     assert not missing, missing
 
 
+def test_rccl_double_exports_what_the_group_binds(pkg):
+    """tests/cpp/rccl_shim.cpp stands in for librccl in the multi-member gather tests: it must export every entry point
+    sp_group.hip looks up (the dlsym names are read from the source), and the product must not name the double."""
+    import subprocess
+    src = open(os.path.join(ROOT, "spectroplot-js_amd", "csrc", "sp_group.hip")).read()
+    names = sorted(set(re.findall(r'dlsym\(lib, "(nccl[A-Za-z]+)"\)', src)))
+    assert len(names) >= 9 and "ncclCommAbort" in names, names
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "tests", "cpp", "_build", "librccl_shim.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert not [n for n in names if n not in exported], (names, exported)
+    assert "rccl_shim" not in src
+
+
 def test_no_oracle_in_product():
     """The product path must not reach into oracle/ (a CPU fallback would void every parity claim)."""
     pdir = os.path.join(ROOT, "spectroplot-js_amd")

@@ -54,7 +54,13 @@ def test_single_gpu_line_has_roofline_and_checks():
         assert r["frac"] == r["frac_one_set"]
     # the profiled child run's own step time sits beside its kernel average: same process, so kernel <= step holds without a band
     assert r["child_run_ms_per_step"] is None or r["kernel_ms"] <= r["child_run_ms_per_step"] * 1.05
-    assert d["value_after_driver_warmup"] > 0.5 * d["value"] and d["ms_per_step_after_driver_warmup"] > 0
+    # `value` is what the command describes: --steps steps right after --warmup steps of the fresh process; the figure
+    # behind the clock spin-up sits beside it and is a separate, later timed region of the same process
+    assert d["warmup"] == 10 and d["steps"] == 50 and "right after --warmup steps" in d["value_is"] and "--warmup 10" in d["value_is"]
+    assert abs(d["value"] - 16384 * 50 / (d["ms_per_step"] * 50e-3)) < 1e-6 * d["value"]
+    assert d["value_steady"] > 0.8 * d["value"] and d["ms_per_step_steady"] > 0 and "spin-up" in d["value_steady_note"]
+    assert d["cold"]["next_steps"] == 9 and d["cold"]["first_step_ms"] > 0          # the cold figures are part of the 10 warm-up steps
+    assert "spinup_steps_untimed" not in d
     # the kernel time is rocprofv3's own figure (a child run of the same command), never an event time with something subtracted;
     # the live event-pair figure of THIS process sits beside it (two runs, and the pair adds its dispatch latency: a band, not an order)
     assert r["kernel_ms_source"].startswith("rocprofv3 --kernel-trace") and abs(r["kernel_ms"] / r["kernel_ms_event_pair"] - 1.0) < 0.2
