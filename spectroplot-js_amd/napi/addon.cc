@@ -209,9 +209,15 @@ HostPool g_pool;
 // 0.25-0.3 ms of an average config-2 message, seen as `_request` taking 280-350 us instead of 40 (tools/js_message_stages.js cfg2,
 // profiles/r05_host_path.txt).  At 6 MiB it runs about every tenth reply and the pool holds ten to twelve blocks (0.7 GiB of host
 // memory for 64-MiB replies) instead of five or six; the blocks still return by collection only.
+// The cap grows with the reply beyond 60 MiB - weight = max(cap, size / 10) - so that the collector still runs about every tenth reply
+// whatever a reply weighs: with a flat 6 MiB, ten 2-GiB replies (config 5) would be 20 GiB of garbage before V8 looked.
 // SPECTROPLOT_HIP_REPLY_WEIGHT_MB changes the cap (a caller that holds many replies at once can raise it to their real size).
 const size_t g_reply_weight_cap = env_mib("SPECTROPLOT_HIP_REPLY_WEIGHT_MB", 6);
-inline int64_t reply_weight(size_t size) { return (int64_t)(size < g_reply_weight_cap ? size : g_reply_weight_cap); }
+inline int64_t reply_weight(size_t size)
+{
+    const size_t floor_w = size < g_reply_weight_cap ? size : g_reply_weight_cap;
+    return (int64_t)(size / 10 > floor_w ? size / 10 : floor_w);
+}
 struct PoolTag { size_t size; int pin; };
 void pool_free_cb(napi_env env, void *data, void *hint)
 {

@@ -112,7 +112,8 @@ def test_an_rccl_failure_in_a_multi_member_exchange_ends_in_peer_copies(pkg, gol
     ONE entry naming the call, and the next renders do not go back to RCCL."""
     monkeypatch.setenv("RCCL_SHIM_FAIL_" + what, str(k))
     g = pkg.Group([0, 0, 0])
-    _check_group_against_merged_vectors(pkg, golden, g, 3, "device", "peer")
+    # (the staging block of the attempted spectrogram exchange stays allocated: staged_before)
+    _check_group_against_merged_vectors(pkg, golden, g, 3, "device", "peer", staged_before=True)
     note = g.transport_note()
     where = {"SEND": "ncclSend", "RECV": "ncclSend / ncclRecv", "GROUPEND": "ncclGroupEnd", "INIT": "ncclCommInitAll"}[what]
     assert note.count("RCCL not used") == 1 and where in note and "(shim)" in note, note
@@ -141,7 +142,7 @@ def test_members_the_root_cannot_address_are_staged_and_retiled(pkg, golden, shi
     if not rccl:
         monkeypatch.setenv("SPECTROPLOT_HIP_NO_RCCL", "1")
     g = pkg.Group([0] * 8)
-    _check_group_against_merged_vectors(pkg, golden, g, 8, "device", "rccl" if rccl else "peer")
+    _check_group_against_merged_vectors(pkg, golden, g, 8, "device", "rccl" if rccl else "peer", staged_before=True)
     assert "SPECTROPLOT_HIP_ASSUME_NO_PEER" in g.transport_note()
     strips = max(7 * 4 * (c["width"] // 8) * c["n"] for c in _merged_cases(golden, 8) if not c["waterfall"])
     assert g.root_bytes()[1] == strips + 16 + 256, g.root_bytes()
