@@ -748,6 +748,10 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
     {
         float ms = 0;
         if (hipEventElapsedTime(&ms, root.rendered, g->gathered) == hipSuccess) g->t_gather = ms;
+        // members that share the root's device render one after the other: the gather starts when the LAST of them has rendered
+        // (events of one device can be compared; on distinct devices the members render side by side and the root's event stands for all)
+        for (Member &mb : g->m)
+            if (mb.device == root.device && hipEventElapsedTime(&ms, mb.rendered, g->gathered) == hipSuccess && ms < g->t_gather) g->t_gather = ms;
         if (hipEventElapsedTime(&ms, g->gathered, g->downloaded) == hipSuccess) g->t_download = ms;
         (void)hipGetLastError();
     }

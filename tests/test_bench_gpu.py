@@ -64,8 +64,9 @@ def test_single_gpu_line_has_roofline_and_checks():
     # the kernel time is rocprofv3's own figure (a child run of the same command), never an event time with something subtracted;
     # the live event-pair figure of THIS process sits beside it (two runs, and the pair adds its dispatch latency: a band, not an order)
     assert r["kernel_ms_source"].startswith("rocprofv3 --kernel-trace") and abs(r["kernel_ms"] / r["kernel_ms_event_pair"] - 1.0) < 0.2
-    # one kernel per step: the step is the kernel (plus launch gaps), not the kernel plus a finish launch
-    assert d["ms_per_step"] < 1.08 * r["kernel_ms"]
+    # one kernel per step: the step is the kernel (plus launch gaps), not the kernel plus a finish launch - at steady clocks, as the
+    # kernel average is; right after 10 warm-up steps the shader clock still ramps and `value` says what that costs (5-15 %)
+    assert d["ms_per_step_steady"] < 1.08 * r["kernel_ms"] and d["ms_per_step"] < 1.35 * r["kernel_ms"]
     rot = r["rotating"]
     assert rot["sets"] == 3 and rot["working_set_MiB"] > 256 and 0.8 < rot["ratio"] < 1.3 and "kernel duration" in rot["verdict"]
     t = d["two_in_flight"]
