@@ -11,7 +11,8 @@
  *   sp_format_parse          lib/samples.js:22-162      the format-name table (aliases, unknown -> CU8)
  *   sp_slice_bounds          lib/samples.js:253-258     SampleView.slice: the caller's per-worker byte range
  *   sp_window                lib/windows.js:14-88       named taper generators (optional sugar; the wire carries arrays)
- *   sp_cmap, sp_cmap_key     lib/cube1cmap.js, lib/matplotlibcmaps.js, lib/soxcmap.js, lib/naivecmap.js, lib/utils.js:25-40
+ *   sp_cmap, sp_cmap_key     lib/cube1cmap.js, lib/matplotlibcmaps.js, lib/parabolacmap.js (tables), lib/utils.js:25-40
+ *   sp_cmap_generate         lib/soxcmap.js:12-49, lib/naivecmap.js:13-81   the computed maps, evaluated (sp_cmap serves them from here)
  *   sp_render_named          lib/spectroplot.js:1113-1146, 1213-1226   the caller's message assembly from option names
  *   sp_named_resolve         lib/spectroplot.js:238-264, lib/utils.js:25-40   option name -> generator / table entry, with the defaults
  *   sp_twiddles              lib/fft_nayuki.js:42-47    cos/sin tables (exposed for tests)
@@ -126,6 +127,12 @@ int sp_window(const char *name, int32_t n, double *window, double *weight);
 int sp_cmap_count(void);
 const char *sp_cmap_key(int32_t index);
 int sp_cmap(const char *name, uint8_t *rgb, int32_t capacity_entries, int32_t *lut_len);
+/*
+ * The reference's computed colour maps as the functions they are (lib/soxcmap.js:12-49 `sox_cmap`; lib/naivecmap.js:13-81 `naive_cmap`,
+ * `grayscale_cmap`, `roentgen_cmap`, `phosphor_cmap`): `stops` entries (the reference exports them at 256) of r, g, b into rgb[3 * stops].
+ * sp_cmap serves these five from the same generators; SP_ERR_UNSUPPORTED for any other key (the other maps are literal tables there too).
+ */
+int sp_cmap_generate(const char *key, int32_t stops, uint8_t *rgb);
 /* cosTable / sinTable of the reference's FFT object, n/2 entries each. */
 int sp_twiddles(int32_t n, double *cos_table, double *sin_table);
 /* The engine's Math.log10 as restated by this library (exposed so tests can pin it). */

@@ -80,6 +80,12 @@ class Library:
         L.sp_twiddles.argtypes = [i32, vp, vp]
         L.sp_js_log10.restype = dbl
         L.sp_js_log10.argtypes = [dbl]
+        L.sp_cmap_count.restype = C.c_int
+        L.sp_cmap_key.restype = C.c_char_p
+        L.sp_cmap_key.argtypes = [i32]
+        L.sp_cmap.argtypes = [C.c_char_p, vp, i32, C.POINTER(i32)]
+        L.sp_cmap_generate.argtypes = [C.c_char_p, i32, vp]
+        L.sp_plan_execute_from_host.argtypes = [vp, vp, sz, i32, C.POINTER(_Reply)]
         L.sp_device_count.argtypes = [C.POINTER(i32)]
         L.sp_context_create.argtypes = [i32, C.POINTER(vp)]
         L.sp_context_destroy.argtypes = [vp]

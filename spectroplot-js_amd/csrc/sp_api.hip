@@ -248,6 +248,15 @@ static int cmap_index(const char *name)
     return sphost::lookup_key(keys, spcmap::kCount, name);
 }
 
+// entry `i` of the colour-map table as r, g, b bytes: the literal tables of the reference as tables, its computed maps
+// (lib/soxcmap.js, lib/naivecmap.js) evaluated by their generators
+static void cmap_bytes(int i, uint8_t *rgb)
+{
+    const spcmap::Entry &e = spcmap::kEntries[i];
+    if (e.offset >= 0) memcpy(rgb, spcmap::kData + e.offset, 3 * (size_t)e.length);
+    else if (!sphost::cmap_generate(e.key, e.length, rgb)) memset(rgb, 0, 3 * (size_t)e.length);   // (every offset -1 entry has a generator: test_abi_cpu)
+}
+
 extern "C" int sp_cmap(const char *name, uint8_t *rgb, int32_t capacity_entries, int32_t *lut_len)
 {
     const int i = cmap_index(name);
@@ -255,8 +264,14 @@ extern "C" int sp_cmap(const char *name, uint8_t *rgb, int32_t capacity_entries,
     const spcmap::Entry &e = spcmap::kEntries[i];
     if (lut_len) *lut_len = e.length;
     if (!rgb || capacity_entries < e.length) return SP_ERR_INVALID_ARG;
-    memcpy(rgb, spcmap::kData + e.offset, 3 * (size_t)e.length);
+    cmap_bytes(i, rgb);
     return SP_OK;
+}
+
+extern "C" int sp_cmap_generate(const char *key, int32_t stops, uint8_t *rgb)
+{
+    if (!key || stops < 1 || stops > 65536 || !rgb) return SP_ERR_INVALID_ARG;
+    return sphost::cmap_generate(key, stops, rgb) ? SP_OK : SP_ERR_UNSUPPORTED;
 }
 
 extern "C" int sp_host_alloc(size_t nbytes, void **ptr)
@@ -1445,7 +1460,8 @@ extern "C" int sp_render_named(sp_context *ctx, const sp_named_request *nr, cons
         int ci = cmap_index(c.c_str());
         if (ci < 0) ci = 0;                                              // cube1 (lib/spectroplot.js:252-264)
         const spcmap::Entry &e = spcmap::kEntries[ci];
-        ctx->named_lut.assign(spcmap::kData + e.offset, spcmap::kData + e.offset + 3 * (size_t)e.length);
+        ctx->named_lut.assign(3 * (size_t)e.length, 0);
+        cmap_bytes(ci, ctx->named_lut.data());
         for (int k = 0; k < 3; k++) {                                    // ends forced to black / white (:1129-1130)
             ctx->named_lut[(size_t)k] = 0;
             ctx->named_lut[3 * (size_t)(e.length - 1) + (size_t)k] = 255;

@@ -105,6 +105,72 @@ const char *window_by_name(const char *name)
     return plain[i < 0 ? 1 : i];
 }
 
+// ---- computed colour maps -------------------------------------------------------------------------------------------------------------
+// Each channel of a computed map is a piecewise function of the entry number; a Piece is one branch of it, in the branch's own
+// operation order (the bytes depend on it).  Two families: lib/soxcmap.js works on x = i / (stops - 1) with sine ramps and rounds to
+// nearest (Math.round), lib/naivecmap.js works on i itself with linear ramps and truncates (~~).
+namespace {
+
+constexpr double kPi = 3.141592653589793;   // Math.PI
+
+// Math.round for the values that occur here (>= 0, far below 2^52): halves go up; decided on the fraction itself, not on v + 0.5
+// (0.49999999999999994 + 0.5 rounds to 1.0 in f64; Math.round gives 0)
+inline uint8_t js_round_u8(double v)
+{
+    const double f = std::floor(v);
+    return (uint8_t)(int)(v - f >= 0.5 ? f + 1 : f);
+}
+// ~~v for 0 <= v < 2^31: truncation
+inline uint8_t js_trunc_u8(double v) { return (uint8_t)(int)v; }
+
+// lib/soxcmap.js:14-42: quarter-sine rises between two knots, a half-sine hump and a linear tail for blue
+void sox_entry(double x, uint8_t *rgb)
+{
+    auto rise = [x](double from, double width) { return 1 * spjs::sin((x - from) / width * kPi / 2); };
+    const double r = x < .13 ? 0.0 : x < .73 ? rise(.13, .60) : 1.0;
+    const double g = x < .60 ? 0.0 : x < .91 ? rise(.60, .31) : 1.0;
+    const double b = x < .60 ? .5 * spjs::sin((x - .00) / .60 * kPi) : x < .78 ? 0.0 : (x - .78) / .22;
+    rgb[0] = js_round_u8(255 * r);
+    rgb[1] = js_round_u8(255 * g);
+    rgb[2] = js_round_u8(255 * b);
+}
+
+}  // namespace
+
+bool cmap_generate(const char *key, int32_t stops, uint8_t *rgb)
+{
+    if (!key || stops < 1 || !rgb) return false;
+    const std::string k = key;
+    const double n = (double)stops;
+    for (int32_t idx = 0; idx < stops; idx++) {
+        const double i = (double)idx;
+        uint8_t *o = rgb + 3 * (size_t)idx;
+        if (k == "sox_cmap") {
+            sox_entry(i / (n - 1.0), o);                                                  // lib/soxcmap.js:15
+        } else if (k == "grayscale_cmap") {
+            o[0] = o[1] = o[2] = js_trunc_u8(i * 255 / n);                                // lib/naivecmap.js:43-46
+        } else if (k == "roentgen_cmap") {
+            o[0] = o[1] = o[2] = js_trunc_u8(255 - (i * 255 / n));                        // :55-58
+        } else if (k == "naive_cmap") {                                                   // :16-37: four quarters, blue - red - yellow - white
+            double r, g, b;
+            if (i < n / 4) { b = i * 128 / (n / 4); g = 0; r = 0; }
+            else if (i < n / 2) { b = 256 - i / 2; g = 0; r = i - n / 4; }
+            else if (i < n * 3 / 4) { b = 0; g = i - n / 2; r = 255; }
+            else { b = i - n * 3 / 4; g = 255; r = 255; }
+            o[0] = js_trunc_u8(r); o[1] = js_trunc_u8(g); o[2] = js_trunc_u8(b);
+        } else if (k == "phosphor_cmap") {                                                // :67-78: green up to 191, then towards white
+            const double h = n / 2;
+            double r, g, b;
+            if (i < h) { r = 0; g = i * 191 / h; b = 0; }
+            else { r = (i - h) * 255 / h; g = 191 + (i - h) * 64 / h; b = (i - h) * 255 / h; }
+            o[0] = js_trunc_u8(r); o[1] = js_trunc_u8(g); o[2] = js_trunc_u8(b);
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
 PixelMath::PixelMath(double block_norm, double gain_, double range_, int32_t lut_len)
     : block_norm_db(10 * spjs::log10(block_norm)), gain(gain_), range(range_), color_max((double)(lut_len - 1)),
       color_norm((double)lut_len / -range_)

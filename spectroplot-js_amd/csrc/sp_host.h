@@ -27,6 +27,11 @@ int32_t lookup_key(const char *const *keys, int32_t count, const char *name);
 // lookup(windows, name) || windows.blackmanHarrisWindow (lib/spectroplot.js:241): the generator's plain name ("hann", ...)
 const char *window_by_name(const char *name);
 
+// The reference's COMPUTED colour maps (lib/soxcmap.js:12-49 `sox`, lib/naivecmap.js:13-81 `naive`, `grayscale`, `roentgen`,
+// `phosphor`): `stops` entries of r, g, b as those functions evaluate them - the engine's Math.sin, Math.round (floor(x + 0.5)) and
+// `~~` (truncation) included.  `key` is the map's key in the reference's table ("sox_cmap", ...).  false: not a computed map.
+bool cmap_generate(const char *key, int32_t stops, uint8_t *rgb);
+
 // The per-pixel arithmetic of lib/worker.js:92-113 as a function of abs2 = re^2 + im^2.
 struct PixelMath {
     double block_norm_db;   // 10 * log10(block_norm)                      worker.js:31

@@ -120,6 +120,74 @@ def test_fails_loudly_without_device(pkg):
         pkg.HipWorker(0)
 
 
+def test_colour_maps_tables_and_generators(pkg, golden):
+    """All 14 colour maps of the reference through sp_cmap against the bytes its own modules evaluate to (tests/golden/cmaps.bin).  Nine
+    are literal tables in the reference and here; the five it COMPUTES (lib/soxcmap.js:12-49, lib/naivecmap.js:13-81) are evaluated by
+    the library's generators (no bytes of them in csrc/sp_cmap_tables.h), also at other stop counts - checked there against the same
+    IEEE-double arithmetic written out in Python (the reference only exports the 256-stop evaluations)."""
+    import math
+    L = pkg.Library.get().L
+    hdr = open(os.path.join(ROOT, "spectroplot-js_amd", "csrc", "sp_cmap_tables.h")).read()
+    computed = ["sox_cmap", "grayscale_cmap", "naive_cmap", "phosphor_cmap", "roentgen_cmap"]
+    for k in computed:
+        assert '{"%s", 256, -1}' % k in hdr, k
+    assert L.sp_cmap_count() == 14 == len(golden.cmap_index)
+    for i in range(14):
+        key = L.sp_cmap_key(i).decode()
+        e = golden.cmap_index[key]
+        want = golden.cmap_bin[e["offset"]:e["offset"] + 3 * e["length"]]
+        got = np.zeros(3 * e["length"], np.uint8)
+        n = C.c_int32()
+        assert L.sp_cmap(key.encode(), got.ctypes.data_as(C.c_void_p), e["length"], C.byref(n)) == 0 and n.value == e["length"], key
+        assert np.array_equal(got, want), key
+        gen = np.zeros(3 * 256, np.uint8)
+        rc = L.sp_cmap_generate(key.encode(), 256, gen.ctypes.data_as(C.c_void_p))
+        assert rc == (0 if key in computed else -4), (key, rc)
+        if key in computed:
+            assert np.array_equal(gen, want), key
+
+    def trunc_family(key, stops):
+        out = []
+        for i in range(stops):
+            if key == "grayscale_cmap":
+                c = i * 255 / stops
+                out += [int(c)] * 3
+            elif key == "roentgen_cmap":
+                c = 255 - (i * 255 / stops)
+                out += [int(c)] * 3
+            elif key == "naive_cmap":
+                if i < stops / 4:
+                    r, g, b = 0, 0, i * 128 / (stops / 4)
+                elif i < stops / 2:
+                    r, g, b = i - stops / 4, 0, 256 - i / 2
+                elif i < stops * 3 / 4:
+                    r, g, b = 255, i - stops / 2, 0
+                else:
+                    r, g, b = 255, 255, i - stops * 3 / 4
+                out += [int(r), int(g), int(b)]
+            elif key == "phosphor_cmap":
+                h = stops / 2
+                if i < h:
+                    r, g, b = 0, i * 191 / h, 0
+                else:
+                    r, g, b = (i - h) * 255 / h, 191 + (i - h) * 64 / h, (i - h) * 255 / h
+                out += [int(r), int(g), int(b)]
+            else:
+                x = i / (stops - 1.0)
+                r = 0 if x < .13 else math.sin((x - .13) / .60 * math.pi / 2) if x < .73 else 1
+                g = 0 if x < .60 else math.sin((x - .60) / .31 * math.pi / 2) if x < .91 else 1
+                b = .5 * math.sin(x / .60 * math.pi) if x < .60 else 0 if x < .78 else (x - .78) / .22
+                out += [int(math.floor(255 * v + 0.5)) for v in (r, g, b)]
+        return np.array(out, np.uint8)
+
+    for stops in (2, 16, 64, 100, 255):        # (naive's blue ramp leaves a byte beyond 256 stops, as it would in the reference)
+        for key in computed:
+            gen = np.zeros(3 * stops, np.uint8)
+            assert L.sp_cmap_generate(key.encode(), stops, gen.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(gen, trunc_family(key, stops)), (key, stops)
+    assert L.sp_cmap_generate(b"sox_cmap", 0, None) == -1
+
+
 def test_option_names_resolve_as_the_reference_resolves_them(pkg):
     """sp_named_resolve (no device needed) against the keys the reference's own lookup() was asked for (tests/golden/parse.json)."""
     import json
