@@ -228,7 +228,8 @@ void sp_plan_destroy(sp_plan *plan);
  * Not capturable: every launch carries the number of its request, which its workgroups compare with what workgroup 0 publishes once it
  * has cleared the reply, so a launch replayed from a hipGraph would not wait.  A call on a stream that is being captured returns
  * SP_ERR_UNSUPPORTED.  (The wait relies on workgroup 0 being dispatched with the first wave of workgroups, as the hardware does; it is
- * bounded - a launch that never sees the number traps instead of hanging.)
+ * bounded - a launch that never sees the number traps instead of hanging.  A trap is a failed launch: the HIP context of the PROCESS is
+ * unusable afterwards - every later call returns SP_ERR_HIP - and can only be had back in a fresh process.)
  */
 int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes, int32_t width, const sp_reply *d_reply);
 /*

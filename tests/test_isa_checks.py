@@ -142,3 +142,77 @@ def test_the_instrumentation_patch_applies_to_the_kernel_sources():
         with open(os.path.join(ROOT, "tools", "experiments", "frames_instrumentation.patch")) as fh:
             r = subprocess.run(["patch", "-p1", "--dry-run", "-s"], cwd=t, stdin=fh, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def _regs(operand):
+    """VGPR numbers an operand names: 'v7' -> {7}, 'v[4:7]' -> {4..7}, anything else -> empty."""
+    import re
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def store_hazards(lines, where=""):
+    """gfx940 / gfx950: a VMEM store of more than 64 bits reads its data registers late - a VALU instruction that overwrites them needs 2
+    wait states behind the store (LLVM's GCNHazardRecognizer inserts them for stores it knows; k_frames issues its write-out stores as
+    inline asm, which it cannot see: ADVICE r5).  Returns the stores followed within 2 wait states by a VALU write to their data."""
+    import re
+    ins = []
+    for ln in lines:
+        t = ln.replace("\t", " ").split("//")[0].strip()
+        if not t or t.endswith(":") or re.match(r"[0-9a-f]+ <", t):
+            continue
+        ins.append(t)
+    bad = []
+    for i, t in enumerate(ins):
+        m = re.match(r"global_store_dwordx[34] (\S+), (v\[\d+:\d+\])", t)
+        if not m:
+            continue
+        data = _regs(m.group(2).rstrip(","))
+        states, j = 0, i + 1
+        while states < 2 and j < len(ins):
+            u = ins[j]
+            nop = re.match(r"s_nop (\d+)", u)
+            if nop:
+                states += int(nop.group(1)) + 1
+                j += 1
+                continue
+            if u.startswith("v_"):
+                ops = [o.strip().rstrip(",") for o in u.split(None, 1)[1].split(",")] if " " in u else []
+                dests = ops[:2] if ("_swap" in u.split()[0]) else ops[:1]
+                written = set().union(*[_regs(o) for o in dests]) if dests else set()
+                if written & data:
+                    bad.append("%s: `%s` then `%s`" % (where, t, u))
+            states += 1
+            j += 1
+    return bad
+
+
+def test_store_hazard_checker_sees_a_data_register_overwritten_too_early():
+    ok = ["\tglobal_store_dwordx4 v1, v[4:7], s[2:3] nt   // 0000: X", "\tv_mov_b32_e32 v9, v4  // 0008", "\ts_nop 0  // 000c",
+          "\tv_mov_b32_e32 v4, v9  // 0010"]
+    assert store_hazards(ok) == []
+    assert len(store_hazards([ok[0], "\tv_mov_b32_e32 v5, v9 // x"])) == 1
+    assert len(store_hazards([ok[0], ok[1], "\tv_add_f64 v[6:7], v[8:9], v[8:9] // x"])) == 1
+    assert store_hazards([ok[0], "\ts_nop 1 // x", "\tv_mov_b32_e32 v5, v9 // x"]) == []
+    assert len(store_hazards([ok[0], "\tv_permlane32_swap_b32_e32 v20, v7 // x"])) == 1
+
+
+def test_no_valu_write_lands_on_the_data_of_a_wide_store_within_two_wait_states():
+    objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "*.o")))
+    if len(objs) < 9:
+        build()
+        objs = sorted(glob.glob(os.path.join(ROOT, "spectroplot-js_amd", "build", "*.o")))
+    objs = [o for o in objs if not o.endswith("sp_host.o")]
+    c = _checker()
+    bad, stores = [], 0
+    for o in objs:
+        lines = c.disassemble(o)
+        stores += sum(1 for ln in lines if "global_store_dwordx4" in ln)
+        bad += store_hazards(lines, os.path.basename(o))
+    assert stores > 500            # the write-out's 16-byte stores are there, in every variant
+    assert not bad, bad[:10]
