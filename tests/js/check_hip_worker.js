@@ -89,7 +89,7 @@ async function main() {
 
     // RCCL, as far as one GPU can execute it: with SPECTROPLOT_HIP_FORCE_RCCL a one-member group moves its own strip and record block
     // through a grouped self ncclSend / ncclRecv on a one-rank communicator (sp_group.hip) - through addon.groupRender
-    let forcedRccl = 0
+    let forcedRccl = 0, multiRccl = 0
     {
         renderSliced.closeGroups()
         process.env.SPECTROPLOT_HIP_FORCE_RCCL = '1'
@@ -106,6 +106,34 @@ async function main() {
             forcedRccl++
         }
         renderSliced.closeGroups()
+        // ... and the MULTI-member exchange (every member but the root sends, the root receives - the spectrogram's strips beside the image,
+        // re-tiled) through the same Node entry point, against the test double of librccl (tests/cpp/rccl_shim.cpp: the real library
+        // refuses one device twice).  The double is built by __graft_entry__.build(); without it this part says so and is skipped.
+        const shim = require('path').join(__dirname, '..', 'cpp', '_build', 'librccl_shim.so')
+        if (require('fs').existsSync(shim)) {
+            process.env.SPECTROPLOT_HIP_RCCL_LIB = shim
+            for (const c of G.spec.worker_cases) {
+                const e = G.expected.find(x => x.name === c.name)
+                if (!e.merged || c.slices < 2) continue
+                const { window: windowc, weight } = O.makeWindow(c.window, c.n)
+                const d = await renderSliced({ buffer: G.makeInput(c), format: c.format, n: c.n, width: c.width, workers: c.slices, device: true,
+                    window: { window: windowc, weight }, cmap: G.getCmap(c, false), gain: c.gain, range: c.range,
+                    channelMode: !!c.channelMode, waterfall: !!c.waterfall })
+                if (G.sha256(d.data) !== e.merged.rgba_sha256) failures.push(`${c.name}: multi-member RCCL rgba`)
+                if (JSON.stringify(d.c_hist) !== JSON.stringify(e.merged.c_hist)) failures.push(`${c.name}: multi-member RCCL c_hist`)
+                if (!G.sameF64(d.dBfs_min, e.merged.dBfs_min) || !G.sameF64(d.dBfs_max, e.merged.dBfs_max)) failures.push(`${c.name}: multi-member RCCL range`)
+                if (d.transport !== 'rccl' || d.transportNote !== '') failures.push(`${c.name}: multi-member RCCL ran as ${d.transport} (${d.transportNote})`)
+                d.replies.forEach((r, i) => {
+                    for (const k of ['gauge_mins', 'gauge_maxs', 'gauge_amps'])
+                        if (Buffer.from(r[k]).toString('hex') !== e.slices[i][k]) failures.push(`${c.name}[${i}]: multi-member RCCL ${k}`)
+                })
+                multiRccl++
+            }
+            renderSliced.closeGroups()
+            delete process.env.SPECTROPLOT_HIP_RCCL_LIB
+        } else {
+            console.error('note: tests/cpp/_build/librccl_shim.so is not built: the multi-member exchange through groupRender was not run')
+        }
         delete process.env.SPECTROPLOT_HIP_FORCE_RCCL
     }
 
@@ -158,7 +186,7 @@ async function main() {
     renderSliced.closeGroups()
     if (deviceMerged < 10) { console.error(`only ${deviceMerged} sliced cases went through the device merge`); process.exit(1) }
     if (forcedRccl < 3) { console.error(`only ${forcedRccl} cases went through the forced RCCL self-exchange`); process.exit(1) }
-    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s); ${deviceMerged} sliced cases also merged on the device and in host memory (sp_group_render_ex), ${forcedRccl} through a forced RCCL self-exchange`)
+    console.log(`HipWorker reproduces ${checked} golden worker vectors bit-for-bit on ${HipWorker.deviceCount()} device(s); ${deviceMerged} sliced cases also merged on the device and in host memory (sp_group_render_ex), ${forcedRccl} through a forced RCCL self-exchange, ${multiRccl} through the multi-member exchange (librccl test double)`)
 }
 
 // (an explicit exit: Node 12 can crash while it tears its environment down when finalizers of collected reply buffers are

@@ -64,9 +64,15 @@ def test_hip_worker_pool_reproduces_the_references_own_caller():
 
 @pytest.mark.gpu
 def test_hip_worker_reproduces_golden_vectors():
+    import re
+    import subprocess as sp
+    sp.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])        # the librccl test double of the multi-member exchange
     out = _node("check_hip_worker.js")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bit-for-bit" in out.stdout
+    # the sliced cases with 2, 3 and 8 workers also went through addon.groupRender's multi-member RCCL exchange (tests/cpp/rccl_shim.cpp)
+    m = re.search(r"(\d+) through the multi-member exchange", out.stdout)
+    assert m and int(m.group(1)) >= 9, out.stdout[-500:]
 
 
 @pytest.mark.gpu
