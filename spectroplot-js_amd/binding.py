@@ -381,6 +381,16 @@ class Plan:
                      dbfs_minmax or None)
         self.ctx._chk(self.ctx.lib.L.sp_plan_execute(self.h, C.c_void_p(d_bytes), nbytes, int(width), C.byref(rep)))
 
+    def execute_from_host(self, data, width, rgba=0, gauge_mins=0, gauge_maxs=0, gauge_amps=0, c_hist=0, cb_hist=0, dbfs_minmax=0):
+        """sp_plan_execute_from_host: `data` is the capture in HOST memory (numpy uint8; it must stay alive until the context has been
+        synchronised), the outputs are device addresses as for execute().  The samples travel in chunks under the renders; a sparse
+        request uploads only what its frames read (ctx.last_upload_bytes())."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        rep = _Reply(rgba or None, gauge_mins or None, gauge_maxs or None, gauge_amps or None, c_hist or None, cb_hist or None,
+                     dbfs_minmax or None)
+        self.ctx._chk(self.ctx.lib.L.sp_plan_execute_from_host(self.h, data.ctypes.data_as(C.c_void_p), data.size, int(width), C.byref(rep)))
+        return data
+
 
 class Group:
     """The caller's sliced render from one process (sp_group_*): one member context per listed device, slice r rendered on member r,

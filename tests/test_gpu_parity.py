@@ -536,6 +536,57 @@ def test_sparse_requests_upload_only_the_frames_they_read(pkg, ctx, monkeypatch,
     assert ctx.last_upload_bytes() == data.size
 
 
+FROM_HOST = [
+    # fmt, n, log2 samples (0: 3 n hop), width, waterfall - what the path takes
+    ("CU8", 1024, 23, 8192, False),       # contiguous upload in four chunks under the renders (16 MiB in)
+    ("CS16", 2048, 22, 3001, True),       # overlapping frames, waterfall, four chunks
+    ("CF32", 1024, 22, 2048, False),      # sparse: only the frames' samples travel, four packed chunks
+    ("CS12", 256, 18, 131, False),        # sparse, one packed chunk
+    ("CU8", 512, 0, 200, False),          # sparse, integer stride
+    ("CF32", 64, 12, 7, False),           # a tiny request: one plain copy
+]
+
+
+@pytest.mark.parametrize("fmt,n,lg,width,wf", FROM_HOST, ids=lambda v: str(v))
+def test_plan_execute_from_host_matches_the_oracle(pkg, ctx, fmt, n, lg, width, wf):
+    """sp_plan_execute_from_host (what a group member does with its slice): the capture in host memory, uploaded in chunks of frames
+    under the renders - a sparse request only the samples its frames read - and every output left in HBM.  Queued twice back to back
+    WITHOUT a synchronisation in between (the second request's first copy must wait for the first request's kernels: they share the
+    context's staging buffer), then everything is compared with the oracle."""
+    S = (1 << lg) if lg else n + (width - 1) * 3 * n
+    data = siggen.generate(fmt, {"kind": "trinoise", "seed": 99 + n, "step": 7321, "gshift": 9, "amp": 0.5, "namp": 0.02}, S)
+    other = siggen.generate(fmt, {"kind": "trinoise", "seed": 1234, "step": 4099, "gshift": 9, "amp": 0.3, "namp": 0.05}, S)
+    win, weight = pyoracle.window("blackmanHarris", n)
+    i = np.arange(256)
+    lut = np.stack([i, 255 - i, (i * 7) & 255], axis=1).astype(np.uint8)
+    want = pyoracle.render(fmt, data, n, win, 1.0 / weight, 6.0, 30.0, lut, width, False, wf)
+    plan = ctx.plan(fmt, n, win, 1.0 / weight, 6.0, 30.0, lut, False, wf)
+    W = width
+    sizes = [4 * W * n, W, W, W, 8 * 256, 8000, 16]
+    ptrs = [ctx.alloc(max(s_, 16)) for s_ in sizes]
+    for p_, s_ in zip(ptrs, sizes):
+        ctx.memset(p_, 0xA5, max(s_, 16))              # (dirty: the kernel clears the reply itself)
+    keep = [plan.execute_from_host(other, W, *ptrs), plan.execute_from_host(data, W, *ptrs)]
+    ctx.synchronize()
+    sw = pkg.parse_format(fmt)[1]
+    sent = ctx.last_upload_bytes()
+    stride = (S - n) / (W - 1)
+    if stride > n and W >= 2:
+        assert W * n * sw <= sent <= W * n * sw * 3 // 2 and sent <= data.size * 3 // 4, (sent, W * n * sw, data.size)
+    else:
+        assert sent == data.size
+    got = {"rgba": ctx.download(ptrs[0], sizes[0]), "gauge_mins": ctx.download(ptrs[1], W), "gauge_maxs": ctx.download(ptrs[2], W),
+           "gauge_amps": ctx.download(ptrs[3], W), "c_hist": ctx.download(ptrs[4], 8 * 256, np.uint64),
+           "cB_hist": ctx.download(ptrs[5], 8000, np.uint64)}
+    mm = ctx.download(ptrs[6], 16, np.float64)
+    got["dBfs_min"], got["dBfs_max"] = float(mm[0]), float(mm[1])
+    _assert_same(got, want)
+    del keep
+    for p_ in ptrs:
+        ctx.free(p_)
+    plan.close()
+
+
 def test_nonfinite_taper_is_exact(pkg, ctx):
     """A caller-supplied taper may hold infinities or NaN (options.windowF is any function).  Inf * 1 + Inf * 0 is NaN in the
     reference's first butterfly, so the kernels that skip the products of (1, 0) butterflies must not serve such a plan."""
