@@ -614,10 +614,12 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
     // image's own device go through the placement kernel (sp_place_strips; a pitched device-to-device copy of 1024 rows of 1 MiB runs at
     // ~120 GB/s here, the kernel at HBM rate: 8 GiB of config-4 strips 129 -> ~10 ms), `cnt` strips laid end to end in one launch;
     // from another device a pitched peer copy.
+    std::string place_error;   // what sp_place_strips said, should it refuse
     auto place = [&](Member &on, int r, const void *src, int cnt = 1) {
         if (req->waterfall) return hipMemcpyAsync(band(r), src, strip_bytes, hipMemcpyDeviceToDevice, on.stream);
         if (on.device == root.device) {
             const int prc = sp_place_strips(on.ctx, (uint8_t *)g->image.p + 4 * sw * (size_t)r, (const uint8_t *)src, cnt, (int32_t)n, width, (int32_t)sw, 0);
+            if (prc != SP_OK) place_error = std::string("sp_place_strips: ") + sp_last_error(on.ctx);
             return prc == SP_OK ? hipSuccess : hipErrorLaunchFailure;
         }
         return hipMemcpy2DAsync(band(r), 4 * W, src, 4 * sw, 4 * sw, n, hipMemcpyDeviceToDevice, on.stream);
@@ -702,7 +704,7 @@ extern "C" int sp_group_render_ex(sp_group *g, const sp_request *req, const uint
     }
     if (e != hipSuccess) {
         drain(g);
-        return gfail(g, SP_ERR_HIP, std::string("group gather: ") + hipGetErrorString(e));
+        return gfail(g, SP_ERR_HIP, std::string("group gather: ") + (place_error.empty() ? hipGetErrorString(e) : place_error.c_str()));
     }
 
     // ---- the caller's merge on the root (lib/spectroplot.js:1229-1238) -----------------------------------------------------------------
