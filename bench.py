@@ -481,8 +481,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # the steady figure (an extra): where the warm-up was shorter than the spin-up, the same --steps again after the rest of it
-    dt_steady, steady_after = dt, args.warmup
+    dt_steady, steady_after, steady_leg = dt, args.warmup, False
     if args.warmup < spinup:
+        steady_leg = True
         for _ in range(spinup + 200 - args.warmup):
             step()
         finish_pending()
@@ -699,7 +700,7 @@ def main():
                         % ("the caller's" if warmup_given else "default", args.warmup),
             "value_steady": world * W * args.steps / dt_steady, "ms_per_step_steady": dt_steady / args.steps * 1e3,
             "value_steady_note": ("the same --steps steps again once the process had run %d steps (the clock spin-up of this configuration: "
-                                  "%d steps + 200): the shader clock no longer ramps" % (steady_after, spinup)) if dt_steady is not dt
+                                  "%d steps + 200): the shader clock no longer ramps" % (steady_after, spinup)) if steady_leg
                                  else "the warm-up covered the clock spin-up of this configuration (%d steps): value_steady is value" % spinup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
