@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
     ap.add_argument("--merge-every", type=int, default=16,
                     help="N > 1: the side-output records of this many renders travel in ONE all-gather (1 = one collective per render)")
+    ap.add_argument("--merge-per-render", action="store_true",
+                    help="N > 1, diagnostic: one sp_merge_replies launch per render of a batch (rounds 1-5) instead of one sp_merge_replies_batch per batch")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "frames"], help="A/B runs: force a device kernel")
     ap.add_argument("--rotate", type=int, default=3,
                     help="N = 1: also time the kernel over this many capture / image sets in rotation, a working set beyond the 256 MiB "
@@ -406,9 +408,13 @@ def main():
 
     # (spectroplot-js_amd/sharding.py RecordBatcher: the batching, the all-gather per batch and the merge one batch later; its shapes
     # and views are exercised on CPU tensors with gloo by tests/test_sharding_gloo.py)
-    batcher = sharding.RecordBatcher(world, M, P, dev, merge_fn=merge_on_device, collectives=dist is not None)
+    def merge_batch_on_device(gathered, ranks, renders, merged_all):
+        # ... a whole batch of renders in ONE launch ([rank][render][record] as the all-gather left it -> [render][record])
+        ctx.merge_replies_batch(gathered.data_ptr(), ranks, renders, L, merged_all.data_ptr())
+
+    batcher = sharding.RecordBatcher(world, M, P, dev, merge_fn=merge_on_device, collectives=dist is not None,
+                                     merge_batch_fn=None if args.merge_per_render else merge_batch_on_device)
     records = batcher.records
-    merged_buf = batcher.merged
 
     rot_sets, rot_k = None, [0]
     if args.rotate_all and args.rotate >= 2:

@@ -22,7 +22,7 @@
  *   sp_plan_execute          lib/worker.js:68-137       the frame loop, operands resident in HBM (benchmarks, multi-GPU)
  *   sp_plan_execute_from_host  lib/worker.js:68-137     the same with the capture in host memory (uploaded in chunks under the renders),
  *                                                        outputs resident in HBM: what a group member does with its slice
- *   sp_merge_replies         lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
+ *   sp_merge_replies(_batch) lib/spectroplot.js:1229-1238   the caller's merge of the slices' histograms and dBfs range, on the device
  *   sp_place_strips          lib/spectroplot.js:1241-1244   the caller's putImageData of every slice's strip, on the device
  *   sp_group_render          lib/spectroplot.js:1206-1244, lib/samples.js:253-258   the caller's sliced render: one slice per device, the
  *                                                        strips gathered device to device (RCCL / peer copies), merged on the root
@@ -247,6 +247,13 @@ int sp_plan_execute_from_host(sp_plan *plan, const uint8_t *bytes, size_t nbytes
  */
 int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t count, int32_t lut_len, uint64_t *d_c_hist, uint64_t *d_cb_hist,
                      double *d_dbfs_minmax);
+/*
+ * The same merge for a BATCH of renders in one launch: d_gathered holds what an all-gather of every rank's batch delivers -
+ * [rank][render][record], `ranks` x `renders` records of lut_len + SP_CB_HIST_SIZE + 2 words - and d_merged receives `renders` merged
+ * records [c_hist | cB_hist | dBfs_min, dBfs_max] end to end (device pointers).  What bench.py --gpus N runs once per collective
+ * (one small launch per render between the frame loops costs a launch gap each).  Asynchronous on the context's stream.
+ */
+int sp_merge_replies_batch(sp_context *ctx, const void *d_gathered, int32_t ranks, int32_t renders, int32_t lut_len, void *d_merged);
 /*
  * The caller's strip placement (lib/spectroplot.js:1241-1244: putImageData(strip, offset, 0), or (0, width - sliceWidth - offset) for the
  * waterfall layout) on device-resident strips: `count` strips of slice_width frames each, laid end to end at d_strips (what a gather of

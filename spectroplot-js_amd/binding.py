@@ -112,6 +112,7 @@ class Library:
         L.sp_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_context_enable_timing.argtypes = [vp, i32]
         L.sp_merge_replies.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.sp_merge_replies_batch.argtypes = [vp, vp, i32, i32, i32, vp]
         L.sp_context_event_pair_overhead_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.sp_place_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
         if not hasattr(L, "sp_group_create"):
@@ -256,6 +257,11 @@ class Context:
         """Device-side merge of `count` slice records [c_hist | cB_hist | dBfs_min, dBfs_max] (the caller's merge, spectroplot.js:1229-1238)."""
         self._chk(self.lib.L.sp_merge_replies(self.h, C.c_void_p(d_records), int(count), int(lut_len), C.c_void_p(d_c_hist or None),
                                               C.c_void_p(d_cb_hist or None), C.c_void_p(d_minmax or None)))
+
+    def merge_replies_batch(self, d_gathered, ranks, renders, lut_len, d_merged):
+        """The same merge for a batch of renders in ONE launch: d_gathered = [rank][render][record] as an all-gather of the ranks' batches
+        delivers it, d_merged = `renders` merged records end to end (sp_merge_replies_batch)."""
+        self._chk(self.lib.L.sp_merge_replies_batch(self.h, C.c_void_p(d_gathered), int(ranks), int(renders), int(lut_len), C.c_void_p(d_merged)))
 
     def place_strips(self, d_image, d_strips, count, n, width, slice_width, waterfall=False):
         """Device-side putImageData of `count` gathered strips (laid end to end at d_strips) into the merged image (spectroplot.js:1241-1244)."""

@@ -876,27 +876,31 @@ extern "C" int sp_plan_execute(sp_plan *plan, const void *d_bytes, size_t nbytes
 
 // ------------------------------------------------------------------------------------------------- merge of slice replies
 
-__global__ void k_merge_replies(const unsigned long long *rec, int count, int lut_len, unsigned long long *c_hist, unsigned long long *cb_hist,
-                                double *minmax)
+// `rank_stride`: 64-bit words between two ranks' records of the same render; blockIdx.y: the render of a batch (its records start
+// blockIdx.y * record_len words into every rank's block, its merged record blockIdx.y * record_len words into the outputs)
+__global__ void k_merge_replies(const unsigned long long *rec, int count, int lut_len, size_t rank_stride, unsigned long long *c_hist,
+                                unsigned long long *cb_hist, double *minmax)
 {
     const int stride = lut_len + SP_CB_HIST_SIZE + 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t shift = (size_t)blockIdx.y * (size_t)stride;
+    rec += shift;
     if (i < lut_len + SP_CB_HIST_SIZE) {
         unsigned long long s = 0;
-        for (int r = 0; r < count; r++) s += rec[(size_t)r * stride + i];                           // spectroplot.js:1232-1238
+        for (int r = 0; r < count; r++) s += rec[(size_t)r * rank_stride + i];                      // spectroplot.js:1232-1238
         if (i < lut_len) {
-            if (c_hist) c_hist[i] = s;
+            if (c_hist) c_hist[shift + i] = s;
         } else if (cb_hist) {
-            cb_hist[i - lut_len] = s;
+            cb_hist[shift + i - lut_len] = s;
         }
     } else if (i < stride && minmax) {
         const int k = i - (lut_len + SP_CB_HIST_SIZE);                                              // 0: min, 1: max
         double v = __longlong_as_double((long long)rec[i]);
         for (int r = 1; r < count; r++) {
-            const double w = __longlong_as_double((long long)rec[(size_t)r * stride + i]);
+            const double w = __longlong_as_double((long long)rec[(size_t)r * rank_stride + i]);
             v = k == 0 ? (w < v ? w : v) : (w > v ? w : v);                                         // the `<` / `>` updates of :1230-1231
         }
-        minmax[k] = v;
+        minmax[shift + k] = v;
     }
 }
 
@@ -907,8 +911,23 @@ extern "C" int sp_merge_replies(sp_context *ctx, const void *d_records, int32_t 
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int total = lut_len + SP_CB_HIST_SIZE + 2;
     hipLaunchKernelGGL(k_merge_replies, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const unsigned long long *)d_records, (int)count, (int)lut_len, (unsigned long long *)d_c_hist,
+                       (const unsigned long long *)d_records, (int)count, (int)lut_len, (size_t)total, (unsigned long long *)d_c_hist,
                        (unsigned long long *)d_cb_hist, d_dbfs_minmax);
+    SP_HIP(ctx, hipGetLastError());
+    return SP_OK;
+}
+
+extern "C" int sp_merge_replies_batch(sp_context *ctx, const void *d_gathered, int32_t ranks, int32_t renders, int32_t lut_len, void *d_merged)
+{
+    if (!ctx || !d_gathered || !d_merged || ranks < 1 || renders < 1 || renders > 65535 || lut_len < 1 || lut_len > SP_MAX_LUT)
+        return SP_ERR_INVALID_ARG;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int total = lut_len + SP_CB_HIST_SIZE + 2;
+    unsigned long long *const out = (unsigned long long *)d_merged;
+    // the merged records keep the record layout [c_hist | cB_hist | min, max]: the three outputs are one block, `total` words per render
+    hipLaunchKernelGGL(k_merge_replies, dim3((unsigned)((total + 255) / 256), (unsigned)renders), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)d_gathered, (int)ranks, (int)lut_len, (size_t)renders * (size_t)total, out, out + lut_len,
+                       (double *)(out + lut_len + SP_CB_HIST_SIZE));
     SP_HIP(ctx, hipGetLastError());
     return SP_OK;
 }

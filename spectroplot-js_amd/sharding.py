@@ -85,12 +85,17 @@ class RecordBatcher:
     (`next_record()` names the place); after M renders ONE all_gather_into_tensor ships the batch (queued behind the batch's kernels,
     it runs while the next batch computes: two buffers in rotation) and the batch gathered before it is reduced render by render with
     `merge_fn(by_rank, count, out)` - `by_rank` the `count` ranks' records of one render end to end, `out` the merged record
-    (sp_merge_replies on the device; the caller's merge, lib/spectroplot.js:1229-1238).  With `collectives=False` (one rank, no process
-    group) the records are only kept."""
+    (sp_merge_replies on the device; the caller's merge, lib/spectroplot.js:1229-1238) - or, where the caller has one, with ONE call of
+    `merge_batch_fn(gathered, ranks, renders, merged_all)` per batch (`gathered` = [rank][M][record] exactly as the all-gather left it,
+    `merged_all` = [M][record]; only the first `renders` of a partial batch are meaningful): sp_merge_replies_batch, one launch instead
+    of M launches and a re-ordering copy between the frame loops.  With `collectives=False` (one rank, no process group) the records are
+    only kept."""
 
-    def __init__(self, world, renders_per_collective, record_len, device, merge_fn=None, group=None, collectives=True):
+    def __init__(self, world, renders_per_collective, record_len, device, merge_fn=None, group=None, collectives=True, merge_batch_fn=None):
         self.world, self.M, self.P = int(world), max(1, int(renders_per_collective)), int(record_len)
         self.group, self.merge_fn, self.collectives = group, merge_fn, bool(collectives)
+        self.merge_batch_fn = merge_batch_fn
+        self.merged_all = torch.zeros(self.M * self.P, dtype=torch.int64, device=device) if merge_batch_fn is not None else None
         self.records = [torch.zeros(self.M * self.P, dtype=torch.int64, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.M * self.P, dtype=torch.int64, device=device) for _ in range(2)] if collectives else None
         self.merged = torch.zeros(self.P, dtype=torch.int64, device=device)
@@ -107,6 +112,11 @@ class RecordBatcher:
         return g.view(self.world, self.M, self.P).transpose(0, 1).contiguous() if self.M > 1 else g.view(1, self.world, self.P)
 
     def _merge(self, slot, count):
+        if self.merge_batch_fn is not None:
+            # (a partial batch's trailing records are stale on every rank alike: they are merged too and never looked at)
+            self.merge_batch_fn(self.gathered[slot], self.world, self.M, self.merged_all)
+            self.merged = self.merged_all[(count - 1) * self.P:count * self.P]
+            return
         b = self.by_render(slot)
         for j in range(count):
             self.merge_fn(b[j].reshape(-1), self.world, self.merged)

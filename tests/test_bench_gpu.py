@@ -80,9 +80,10 @@ def test_single_gpu_line_has_roofline_and_checks():
     assert v is None or (v["bound"] == "f64 VALU issue" and v["fused_f64_insts"] < 2e-3 * v["f64_wave_insts"] and 0.0 < v["frac"] < 1.0)
 
 
-@pytest.mark.parametrize("merge_every", [1, 3])
-def test_two_ranks_on_one_gpu_merge_every_render(merge_every):
-    d = run_bench("--gpus", "2", "--oversubscribe", "--backend", "gloo", "--steps", "20", "--warmup", "5", "--merge-every", str(merge_every))
+@pytest.mark.parametrize("merge_every,per_render", [(1, False), (3, False), (3, True)], ids=["every_render", "batches_of_3", "batches_of_3_merged_per_render"])
+def test_two_ranks_on_one_gpu_merge_every_render(merge_every, per_render):
+    d = run_bench("--gpus", "2", "--oversubscribe", "--backend", "gloo", "--steps", "20", "--warmup", "5", "--merge-every", str(merge_every),
+                  *(["--merge-per-render"] if per_render else []))
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["renders_per_collective"] == merge_every
     assert d["checks"]["c_hist_sum"] == d["checks"]["expected"] == 2 * 16384 * 1024      # the LAST render's merged histogram
     assert d["rgba_gather_ms"] > 0

@@ -212,6 +212,33 @@ def test_group_rccl_failures_end_in_peer_copies_with_a_note(pkg, golden, monkeyp
     g.close()
 
 
+def test_batched_merge_equals_the_merge_render_by_render(pkg, ctx):
+    """sp_merge_replies_batch (one launch per collective in bench.py --gpus N) against sp_merge_replies called per render on the
+    re-ordered records: sums of the histograms, min / max of the dBfs ranges (lib/spectroplot.js:1229-1238), for 1 ... 8 ranks and
+    batches of 1, 3 and 16 renders, LUTs of 2, 64 and 256 entries."""
+    rs = np.random.RandomState(5)
+    for ranks, renders, L in ((1, 1, 256), (2, 3, 64), (3, 16, 256), (8, 16, 256), (8, 5, 2)):
+        P = L + 1000 + 2
+        g = rs.randint(0, 1 << 40, size=(ranks, renders, P)).astype(np.uint64)
+        mm = -200.0 * rs.rand(ranks, renders, 2)
+        g[:, :, L + 1000:] = mm.view(np.uint64)
+        d_g, d_out, d_one, d_rec = ctx.alloc(g.nbytes), ctx.alloc(8 * renders * P), ctx.alloc(8 * P), ctx.alloc(8 * ranks * P)
+        ctx.upload(d_g, g.reshape(-1).view(np.uint8))
+        ctx.merge_replies_batch(d_g, ranks, renders, L, d_out)
+        ctx.synchronize()
+        got = ctx.download(d_out, 8 * renders * P, np.uint64).reshape(renders, P)
+        for j in range(renders):
+            ctx.upload(d_rec, np.ascontiguousarray(g[:, j, :]).reshape(-1).view(np.uint8))
+            ctx.merge_replies(d_rec, ranks, L, d_one, d_one + 8 * L, d_one + 8 * (L + 1000))
+            ctx.synchronize()
+            one = ctx.download(d_one, 8 * P, np.uint64)
+            assert np.array_equal(got[j], one), (ranks, renders, L, j)
+            assert np.array_equal(got[j][:L + 1000], g[:, j, :L + 1000].sum(axis=0, dtype=np.uint64))
+            assert got[j][L + 1000:].view(np.float64)[0] == mm[:, j, 0].min() and got[j][L + 1000:].view(np.float64)[1] == mm[:, j, 1].max()
+        for p_ in (d_g, d_out, d_one, d_rec):
+            ctx.free(p_)
+
+
 def test_group_render_rejects_what_it_cannot_read(pkg):
     """A request with a null taper / colour map is an invalid argument, not a crash - also once a plan is cached."""
     import ctypes as C

@@ -204,7 +204,30 @@ def _batcher_rank(rank, world, port, steps, per, out_dir):
                                             torch.maximum(mm[:, 1].max(), torch.tensor(-200.0, dtype=torch.float64))])
         merges.append(out.clone())
 
+    def merge_batch_fn(gathered, ranks, renders, merged_all):   # sp_merge_replies_batch in torch: [rank][render][record] -> [render][record]
+        assert gathered.shape == (ranks * renders * P,) and merged_all.shape == (renders * P,) and ranks == world
+        g = gathered.view(ranks, renders, P)
+        for j in range(renders):
+            merge_fn(g[:, j, :].contiguous().view(-1), ranks, merged_all[j * P:(j + 1) * P])
+            merges.pop()
+
     ok = True
+    # ... the same batches reduced by ONE call per collective (what bench.py does on the device): the last render's merged record must
+    # be the one final_record() names, partial last batch included
+    for M in (1, 3, 16):
+        b = sharding.RecordBatcher(world, M, P, "cpu", merge_fn=merge_fn, merge_batch_fn=merge_batch_fn)
+        for k in range(steps):
+            b.next_record().copy_(record_of(rank, k))
+            b.rendered()
+            if k % 7 == 6:
+                b.finish()                               # (a caller may finish in the middle: partial batches, then a fresh one)
+        b.finish()
+        want = torch.zeros(P, dtype=torch.int64)
+        k = steps - 1
+        want[:L + CB] = sum(record_of(r, k)[:L + CB] for r in range(world))
+        f64(want[L + CB:])[:] = torch.tensor([min(0.0, min(-1.5 * r - k for r in range(world))),
+                                             max(-200.0, max(-150.0 + r + 2.0 * k for r in range(world)))], dtype=torch.float64)
+        ok &= bool(torch.equal(b.final_record(), want))
     for M in (1, 3, 16):
         merges.clear()
         b = sharding.RecordBatcher(world, M, P, "cpu", merge_fn=merge_fn)
