@@ -308,8 +308,10 @@ def main():
                     help="diagnostic: run the collectives of the N > 1 path with N = 1 too (one-rank RCCL group: exercises the nccl code path on a one-GPU box)")
     ap.add_argument("--waterfall", action="store_true", help="diagnostic: waterfall layout instead of spectrogram")
     ap.add_argument("--no-rgba", action="store_true", help="diagnostic: skip the image output (INVALID as a benchmark)")
-    ap.add_argument("--merge-every", type=int, default=16,
-                    help="N > 1: the side-output records of this many renders travel in ONE all-gather (1 = one collective per render)")
+    ap.add_argument("--merge-every", type=int, default=64,
+                    help="N > 1: the side-output records of this many renders travel in ONE all-gather and are merged in ONE launch "
+                         "(1 = one collective per render; default 64: what a collective costs the frame loops - its kernel needs CUs that "
+                         "the frame loop fills completely - is paid once per batch)")
     ap.add_argument("--merge-per-render", action="store_true",
                     help="N > 1, diagnostic: one sp_merge_replies launch per render of a batch (rounds 1-5) instead of one sp_merge_replies_batch per batch")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scratch", "frames"], help="A/B runs: force a device kernel")
