@@ -134,7 +134,7 @@ def e2e_dropin():
         return {"failed": repr(e)}
 
 
-PROFILE_TAGS = ("r05", "r04", "r03")   # profiles/<tag>_<config>_{traffic,valu}.json: committed rocprofv3 --pmc summaries of this same command (newest first)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03")   # profiles/<tag>_<config>_{traffic,valu}.json: committed rocprofv3 --pmc summaries of this same command (newest first)
 
 
 def rocprof_kernel_us(argv_config):
